@@ -1,0 +1,255 @@
+"""ctypes binding of libgmrhip.so (include/gmr_hip.h).  No torch, no fallback: if the library is
+missing or no GPU is visible the product path raises -- there is deliberately no CPU path here."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .ik_config import MODEL_DTYPE, TASKSET_DTYPE
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgmrhip.so")
+_lib = None
+
+FLAG_OFFSET_TO_GROUND = 1
+STATUS_OK, STATUS_QP_FAILED, STATUS_QP_MAXITER = 0, -1, -2
+
+
+class GmrHipError(RuntimeError):
+    pass
+
+
+_SIGS = {
+    "gmr_last_error": (C.c_char_p, []),
+    "gmr_backend_info": (C.c_char_p, []),
+    "gmr_device_count": (C.c_int, []),
+    "gmr_set_device": (C.c_int, [C.c_int]),
+    "gmr_sizeof_model": (C.c_size_t, []),
+    "gmr_sizeof_taskset": (C.c_size_t, []),
+    "gmr_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "gmr_free": (C.c_int, [C.c_void_p]),
+    "gmr_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "gmr_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gmr_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gmr_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "gmr_stream_destroy": (C.c_int, [C.c_void_p]),
+    "gmr_stream_sync": (C.c_int, [C.c_void_p]),
+    "gmr_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "gmr_event_destroy": (C.c_int, [C.c_void_p]),
+    "gmr_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gmr_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "gmr_solver_create": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gmr_solver_destroy": (C.c_int, [C.c_void_p]),
+    "gmr_solver_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gmr_retarget_lds_bytes": (C.c_int, [C.c_void_p]),
+    "gmr_retarget_streams_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gmr_retarget_streams": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gmr_fk_create": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                C.POINTER(C.c_void_p)]),
+    "gmr_fk_destroy": (C.c_int, [C.c_void_p]),
+    "gmr_fk_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    "gmr_fk_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+def lib():
+    """Load libgmrhip.so (raises GmrHipError when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GmrHipError(
+                f"{LIB_PATH} not found: build it with `python -m general_motion_retargeting_amd.build` "
+                "(there is no CPU fallback in the product path)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.gmr_sizeof_model() != MODEL_DTYPE.itemsize or L.gmr_sizeof_taskset() != TASKSET_DTYPE.itemsize:
+            raise GmrHipError("ABI mismatch between libgmrhip.so and the Python struct layouts")
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise GmrHipError(f"libgmrhip error {rc}: {lib().gmr_last_error().decode()}")
+
+
+def require_gpu() -> None:
+    if lib().gmr_device_count() <= 0:
+        raise GmrHipError("no HIP device visible: the product path needs an MI355X (no CPU fallback)")
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceBuffer:
+    """Owned device allocation (hipMalloc through the C-ABI)."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().gmr_malloc(C.byref(p), self.nbytes))
+        self.ptr = p
+
+    @classmethod
+    def from_host(cls, a: np.ndarray, stream=None) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes)
+        check(lib().gmr_memcpy_h2d(b.ptr, _ptr(a), a.nbytes, stream))
+        check(lib().gmr_stream_sync(stream))
+        return b
+
+    def to_host(self, shape, dtype, stream=None) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(lib().gmr_memcpy_d2h(_ptr(out), self.ptr, out.nbytes, stream))
+        check(lib().gmr_stream_sync(stream))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().gmr_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        p = C.c_void_p()
+        check(lib().gmr_event_create(C.byref(p)))
+        self.ptr = p
+
+    def record(self, stream=None):
+        check(lib().gmr_event_record(self.ptr, stream))
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = C.c_float()
+        check(lib().gmr_event_elapsed_ms(self.ptr, stop.ptr, C.byref(ms)))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().gmr_event_destroy(self.ptr)
+        except Exception:
+            pass
+
+
+class Solver:
+    """Device-resident (robot model, task set): handle behind gmr_solver_create."""
+
+    def __init__(self, model_blob: np.ndarray, taskset_blob: np.ndarray):
+        require_gpu()
+        assert model_blob.dtype == MODEL_DTYPE and taskset_blob.dtype == TASKSET_DTYPE
+        self.model_blob = np.ascontiguousarray(model_blob)
+        self.taskset_blob = np.ascontiguousarray(taskset_blob)
+        h = C.c_void_p()
+        check(lib().gmr_solver_create(_ptr(self.model_blob), _ptr(self.taskset_blob), C.byref(h)))
+        self.handle = h
+        self.nq = int(model_blob["nq"][0])
+        self.nv = int(model_blob["nv"][0])
+        self.nhuman = int(taskset_blob["nhuman"][0])
+
+    @property
+    def lds_bytes(self) -> int:
+        return int(lib().gmr_retarget_lds_bytes(self.handle))
+
+    def retarget_streams(self, q0, human, lens=None, flags: int = 0):
+        """Host arrays in/out: q0[S,nq], human[S,T,nhuman,7] -> q_out[S,T,nq], nsolve[S,T,2], status[S]."""
+        human = np.ascontiguousarray(human, dtype=np.float64)
+        if human.ndim != 4 or human.shape[2] != self.nhuman or human.shape[3] != 7:
+            raise ValueError(f"human must be [S,T,{self.nhuman},7], got {human.shape}")
+        S, T = human.shape[:2]
+        q0 = np.ascontiguousarray(q0, dtype=np.float64)
+        if q0.shape != (S, self.nq):
+            raise ValueError(f"q0 must be [{S},{self.nq}], got {q0.shape}")
+        if lens is not None:
+            lens = np.ascontiguousarray(lens, dtype=np.int32)
+            if lens.shape != (S,):
+                raise ValueError("lens must be [S]")
+        q_out = np.zeros((S, T, self.nq), dtype=np.float64)
+        nsolve = np.zeros((S, T, 2), dtype=np.int32)
+        status = np.zeros(S, dtype=np.int32)
+        check(lib().gmr_retarget_streams(self.handle, S, T, _ptr(q0), _ptr(human), _ptr(lens), int(flags),
+                                         _ptr(q_out), _ptr(nsolve), _ptr(status)))
+        return q_out, nsolve, status
+
+    def retarget_streams_dev(self, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream=None):
+        """Device pointers (DeviceBuffer or raw c_void_p); asynchronous on `stream`."""
+        def p(x):
+            return x.ptr if isinstance(x, DeviceBuffer) else x
+        check(lib().gmr_retarget_streams_dev(self.handle, int(S), int(T), p(d_q0), p(d_human), p(d_len), int(flags),
+                                             p(d_q_out), p(d_nsolve), p(d_status), stream))
+
+    def close(self):
+        if self.handle:
+            lib().gmr_solver_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FkHandle:
+    """Device-resident KinematicsModel tree: handle behind gmr_fk_create."""
+
+    def __init__(self, tree: dict):
+        require_gpu()
+        self.nbody = int(len(tree["parent"]))
+        self.ndof = int((np.asarray(tree["dof_dim"]) > 0).sum())
+        self._keep = [np.ascontiguousarray(tree["parent"], dtype=np.int32),
+                      np.ascontiguousarray(tree["local_translation"], dtype=np.float32),
+                      np.ascontiguousarray(tree["local_rotation"], dtype=np.float32),
+                      np.ascontiguousarray(tree["dof_idx"], dtype=np.int32),
+                      np.ascontiguousarray(tree["axis"], dtype=np.float64)]
+        h = C.c_void_p()
+        check(lib().gmr_fk_create(self.nbody, *[_ptr(a) for a in self._keep], self.ndof, C.byref(h)))
+        self.handle = h
+
+    def fk(self, root_pos, root_rot, dof, want_rot=True, want_min_z=False):
+        root_pos = np.ascontiguousarray(root_pos, dtype=np.float32)
+        root_rot = np.ascontiguousarray(root_rot, dtype=np.float32)
+        dof = np.ascontiguousarray(dof, dtype=np.float32)
+        B = root_pos.shape[0]
+        if root_pos.shape != (B, 3) or root_rot.shape != (B, 4) or dof.shape != (B, self.ndof):
+            raise ValueError("shape mismatch in fk inputs")
+        bp = np.zeros((B, self.nbody, 3), dtype=np.float32)
+        br = np.zeros((B, self.nbody, 4), dtype=np.float32) if want_rot else None
+        mz = np.zeros(1, dtype=np.float32) if want_min_z else None
+        check(lib().gmr_fk_batch(self.handle, B, _ptr(root_pos), _ptr(root_rot), _ptr(dof), _ptr(bp), _ptr(br), _ptr(mz)))
+        return bp, br, (float(mz[0]) if want_min_z else None)
+
+    def fk_dev(self, B, d_root_pos, d_root_rot, d_dof, d_body_pos, d_body_rot=None, d_min_z=None, stream=None):
+        def p(x):
+            return x.ptr if isinstance(x, DeviceBuffer) else x
+        check(lib().gmr_fk_batch_dev(self.handle, int(B), p(d_root_pos), p(d_root_rot), p(d_dof), p(d_body_pos),
+                                     p(d_body_rot), p(d_min_z), stream))
+
+    def close(self):
+        if self.handle:
+            lib().gmr_fk_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,379 @@
+// gmr_abi.hip -- the C-ABI of libgmrhip.so (include/gmr_hip.h): handles, memory/stream/event
+// helpers and the host side of the two launches.  No compute happens here.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../include/gmr_hip.h"
+#include "gmr_fk_tree.h"
+#include "gmr_ik_layout.h"
+
+static_assert(sizeof(gmr_model_t) % 8 == 0, "gmr_model_t must be 8-byte sized");
+static_assert(sizeof(gmr_taskset_t) % 8 == 0, "gmr_taskset_t must be 8-byte sized");
+static_assert(offsetof(gmr_model_t, timestep) % 8 == 0, "double block of gmr_model_t misaligned");
+static_assert(offsetof(gmr_taskset_t, damping) % 8 == 0, "double block of gmr_taskset_t misaligned");
+
+extern "C" hipError_t gmr_launch_ik_streams(const gmr_model_t*, const gmr_taskset_t*, const gmr::IkLayout*, int, int,
+                                            const double*, const double*, const int32_t*, int, double*, int32_t*,
+                                            int32_t*, hipStream_t);
+extern "C" hipError_t gmr_ik_set_max_smem(int bytes);
+extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree*, int, int, int, const float*, const float*, const float*,
+                                          float*, float*, float*, float*, hipStream_t);
+extern "C" int gmr_fk_blocks(int nbody, int B);
+
+namespace {
+thread_local char g_err[512] = "";
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(call)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (call);                                                                   \
+    if (_e != hipSuccess) return fail(GMR_ERR_HIP, "%s: %s", #call, hipGetErrorString(_e));   \
+  } while (0)
+}  // namespace
+
+struct gmr_solver {
+  gmr_model_t model;
+  gmr_taskset_t ts;
+  gmr::IkLayout layout;
+  gmr_model_t* d_model = nullptr;
+  gmr_taskset_t* d_ts = nullptr;
+};
+
+struct gmr_fk {
+  gmr::FkTree tree;
+  gmr::FkTree* d_tree = nullptr;
+  float* d_min_part = nullptr;
+  int min_part_cap = 0;
+};
+
+extern "C" {
+
+const char* gmr_last_error(void) { return g_err; }
+
+const char* gmr_backend_info(void) {
+  static thread_local char buf[256];
+  int dev = -1;
+  hipDeviceProp_t p;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+    snprintf(buf, sizeof buf, "hip:%s device=%d name=%s CUs=%d", p.gcnArchName, dev, p.name, p.multiProcessorCount);
+  else
+    snprintf(buf, sizeof buf, "hip:no-device");
+  return buf;
+}
+
+int gmr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+int gmr_set_device(int device) { HIP_TRY(hipSetDevice(device)); return GMR_OK; }
+size_t gmr_sizeof_model(void) { return sizeof(gmr_model_t); }
+size_t gmr_sizeof_taskset(void) { return sizeof(gmr_taskset_t); }
+
+int gmr_malloc(void** ptr, size_t bytes) {
+  if (!ptr) return fail(GMR_ERR_ARG, "gmr_malloc: null out pointer");
+  HIP_TRY(hipMalloc(ptr, bytes ? bytes : 8));
+  return GMR_OK;
+}
+int gmr_free(void* ptr) { if (ptr) HIP_TRY(hipFree(ptr)); return GMR_OK; }
+int gmr_memset(void* ptr, int value, size_t bytes, void* stream) {
+  HIP_TRY(hipMemsetAsync(ptr, value, bytes, (hipStream_t)stream));
+  return GMR_OK;
+}
+int gmr_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return GMR_OK;
+}
+int gmr_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return GMR_OK;
+}
+int gmr_stream_create(void** stream) {
+  hipStream_t s;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = (void*)s;
+  return GMR_OK;
+}
+int gmr_stream_destroy(void* stream) { HIP_TRY(hipStreamDestroy((hipStream_t)stream)); return GMR_OK; }
+int gmr_stream_sync(void* stream) {
+  if (stream) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  else HIP_TRY(hipDeviceSynchronize());
+  return GMR_OK;
+}
+int gmr_event_create(void** event) {
+  hipEvent_t e;
+  HIP_TRY(hipEventCreate(&e));
+  *event = (void*)e;
+  return GMR_OK;
+}
+int gmr_event_destroy(void* event) { HIP_TRY(hipEventDestroy((hipEvent_t)event)); return GMR_OK; }
+int gmr_event_record(void* event, void* stream) {
+  HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+  return GMR_OK;
+}
+int gmr_event_elapsed_ms(void* start, void* stop, float* ms) {
+  HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
+  HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return GMR_OK;
+}
+
+// ---- solver ---------------------------------------------------------------------------------
+static int validate(const gmr_model_t* m, const gmr_taskset_t* t) {
+  if (!m || !t) return fail(GMR_ERR_ARG, "null model/taskset");
+  if (m->magic != GMR_MAGIC_MODEL || m->version != GMR_ABI_VERSION) return fail(GMR_ERR_ARG, "bad model blob");
+  if (t->magic != GMR_MAGIC_TASKSET || t->version != GMR_ABI_VERSION) return fail(GMR_ERR_ARG, "bad taskset blob");
+  if (m->nbody < 1 || m->nbody > GMR_MAX_BODIES || m->nbody > 64) return fail(GMR_ERR_ARG, "nbody out of range");
+  if (m->nhinge < 0 || m->nhinge > GMR_MAX_HINGES) return fail(GMR_ERR_ARG, "nhinge out of range");
+  if (m->nv != m->nhinge + 6 || m->nq != m->nhinge + 7 || m->nv > 64) return fail(GMR_ERR_ARG, "nq/nv inconsistent");
+  if (!(m->timestep > 0.0)) return fail(GMR_ERR_ARG, "timestep must be positive");
+  if (m->parent[0] != -1) return fail(GMR_ERR_ARG, "body 0 must be the root");
+  for (int b = 1; b < m->nbody; b++) {
+    if (m->parent[b] < 0 || m->parent[b] >= b) return fail(GMR_ERR_ARG, "parent[%d] invalid", b);
+    if (m->depth[b] != m->depth[m->parent[b]] + 1 || m->depth[b] >= GMR_MAX_DEPTH)
+      return fail(GMR_ERR_ARG, "depth[%d] invalid", b);
+    for (int d = 0; d <= m->depth[b]; d++)
+      if (m->chain[b][d] < 0 || m->chain[b][d] >= m->nbody) return fail(GMR_ERR_ARG, "chain[%d][%d] invalid", b, d);
+    if (m->chain[b][m->depth[b]] != b) return fail(GMR_ERR_ARG, "chain[%d] does not end at the body", b);
+    if (m->body_hinge[b] < -1 || m->body_hinge[b] >= m->nhinge) return fail(GMR_ERR_ARG, "body_hinge[%d] invalid", b);
+  }
+  for (int h = 0; h < m->nhinge; h++)
+    if (m->hinge_body[h] < 1 || m->hinge_body[h] >= m->nbody || m->body_hinge[m->hinge_body[h]] != h)
+      return fail(GMR_ERR_ARG, "hinge_body[%d] invalid", h);
+  if (t->nhuman < 1 || t->nhuman > GMR_MAX_HUMAN || t->human_root < 0 || t->human_root >= t->nhuman)
+    return fail(GMR_ERR_ARG, "nhuman/human_root out of range");
+  for (int s = 0; s < 2; s++) {
+    if (t->ntask[s] < 0 || t->ntask[s] > GMR_MAX_TASKS) return fail(GMR_ERR_ARG, "ntask out of range");
+    if (t->use_stage[s] && t->ntask[s] == 0) return fail(GMR_ERR_ARG, "stage %d enabled without tasks", s + 1);
+    if (t->npair[s] < 0 || t->npair[s] > GMR_MAX_PAIRS) return fail(GMR_ERR_ARG, "npair out of range");
+    int p = 0;
+    for (int k = 0; k < t->ntask[s]; k++) {
+      if (t->task_body[s][k] < 0 || t->task_body[s][k] >= m->nbody) return fail(GMR_ERR_ARG, "task body invalid");
+      if (t->task_human[s][k] < 0 || t->task_human[s][k] >= t->nhuman) return fail(GMR_ERR_ARG, "task human invalid");
+      if (t->task_col0[s][k] != p) return fail(GMR_ERR_ARG, "task_col0 not contiguous");
+      int n = t->task_ncol[s][k];
+      if (n < 6 || p + n > t->npair[s]) return fail(GMR_ERR_ARG, "task_ncol invalid");
+      for (int c = 0; c < n; c++) {
+        int d = t->pair_dof[s][p + c];
+        if (t->pair_task[s][p + c] != k || d < 0 || d >= m->nv) return fail(GMR_ERR_ARG, "pair table invalid");
+        if (c > 0 && d <= t->pair_dof[s][p + c - 1]) return fail(GMR_ERR_ARG, "pair dofs not ascending");
+        if (t->pair_index[s][k][d] != p + c) return fail(GMR_ERR_ARG, "pair_index inconsistent");
+      }
+      p += n;
+    }
+    if (p != t->npair[s]) return fail(GMR_ERR_ARG, "npair inconsistent");
+  }
+  if (t->max_iter < 0 || t->max_iter > 1000) return fail(GMR_ERR_ARG, "max_iter out of range");
+  return GMR_OK;
+}
+
+int gmr_solver_create(const gmr_model_t* model, const gmr_taskset_t* taskset, gmr_solver_t** out) {
+  if (!out) return fail(GMR_ERR_ARG, "null out pointer");
+  int rc = validate(model, taskset);
+  if (rc) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(GMR_ERR_NO_DEVICE, "no HIP device visible");
+  gmr_solver* s = new (std::nothrow) gmr_solver;
+  if (!s) return fail(GMR_ERR_ARG, "out of host memory");
+  s->model = *model;
+  s->ts = *taskset;
+  s->layout = gmr::make_ik_layout(s->model, s->ts);
+  if (s->layout.smem_bytes > 160 * 1024) { delete s; return fail(GMR_ERR_ARG, "robot too large for LDS"); }
+  hipError_t e;
+  if ((e = hipMalloc((void**)&s->d_model, sizeof(gmr_model_t))) != hipSuccess ||
+      (e = hipMalloc((void**)&s->d_ts, sizeof(gmr_taskset_t))) != hipSuccess ||
+      (e = hipMemcpy(s->d_model, &s->model, sizeof(gmr_model_t), hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(s->d_ts, &s->ts, sizeof(gmr_taskset_t), hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = gmr_ik_set_max_smem(s->layout.smem_bytes)) != hipSuccess) {
+    if (s->d_model) (void)hipFree(s->d_model);
+    if (s->d_ts) (void)hipFree(s->d_ts);
+    delete s;
+    return fail(GMR_ERR_HIP, "gmr_solver_create: %s", hipGetErrorString(e));
+  }
+  *out = s;
+  return GMR_OK;
+}
+
+int gmr_solver_destroy(gmr_solver_t* s) {
+  if (!s) return GMR_OK;
+  (void)hipFree(s->d_model);
+  (void)hipFree(s->d_ts);
+  delete s;
+  return GMR_OK;
+}
+
+int gmr_solver_dims(const gmr_solver_t* s, int* nq, int* nv, int* nhuman) {
+  if (!s) return fail(GMR_ERR_ARG, "null solver");
+  if (nq) *nq = s->model.nq;
+  if (nv) *nv = s->model.nv;
+  if (nhuman) *nhuman = s->ts.nhuman;
+  return GMR_OK;
+}
+
+int gmr_retarget_lds_bytes(const gmr_solver_t* s) { return s ? s->layout.smem_bytes : 0; }
+
+int gmr_retarget_streams_dev(gmr_solver_t* s, int S, int T, const double* d_q0, const double* d_human,
+                             const int32_t* d_len, int flags, double* d_q_out, int32_t* d_nsolve,
+                             int32_t* d_status, void* stream) {
+  if (!s) return fail(GMR_ERR_ARG, "null solver");
+  if (S < 0 || T < 0) return fail(GMR_ERR_ARG, "negative S/T");
+  if (S == 0 || T == 0) return GMR_OK;
+  if (!d_q0 || !d_human || !d_q_out || !d_nsolve || !d_status) return fail(GMR_ERR_ARG, "null device buffer");
+  HIP_TRY(gmr_launch_ik_streams(s->d_model, s->d_ts, &s->layout, S, T, d_q0, d_human, d_len, flags, d_q_out,
+                                d_nsolve, d_status, (hipStream_t)stream));
+  return GMR_OK;
+}
+
+int gmr_retarget_streams(gmr_solver_t* s, int S, int T, const double* q0, const double* human, const int32_t* len,
+                         int flags, double* q_out, int32_t* nsolve, int32_t* status) {
+  if (!s) return fail(GMR_ERR_ARG, "null solver");
+  if (S < 0 || T < 0) return fail(GMR_ERR_ARG, "negative S/T");
+  if (S == 0 || T == 0) return GMR_OK;
+  if (!q0 || !human || !q_out || !nsolve || !status) return fail(GMR_ERR_ARG, "null host buffer");
+  const size_t nq = s->model.nq, nh = s->ts.nhuman;
+  const size_t b_q0 = (size_t)S * nq * 8, b_h = (size_t)S * T * nh * 7 * 8, b_qo = (size_t)S * T * nq * 8;
+  const size_t b_ns = (size_t)S * T * 2 * 4, b_st = (size_t)S * 4, b_len = (size_t)S * 4;
+  char* d = nullptr;
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  size_t o_q0 = 0, o_h = o_q0 + up(b_q0), o_qo = o_h + up(b_h), o_ns = o_qo + up(b_qo), o_st = o_ns + up(b_ns),
+         o_len = o_st + up(b_st), total = o_len + up(b_len);
+  HIP_TRY(hipMalloc((void**)&d, total));
+  int rc = GMR_OK;
+  hipError_t e;
+  if ((e = hipMemcpy(d + o_q0, q0, b_q0, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(d + o_h, human, b_h, hipMemcpyHostToDevice)) != hipSuccess ||
+      (len && (e = hipMemcpy(d + o_len, len, b_len, hipMemcpyHostToDevice)) != hipSuccess)) {
+    rc = fail(GMR_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
+  }
+  // frames at or beyond len[s] are not touched by the kernel: hand them back as zeros
+  if (rc == GMR_OK && len && (e = hipMemset(d + o_qo, 0, (o_st - o_qo))) != hipSuccess)
+    rc = fail(GMR_ERR_HIP, "memset: %s", hipGetErrorString(e));
+  if (rc == GMR_OK)
+    rc = gmr_retarget_streams_dev(s, S, T, (double*)(d + o_q0), (double*)(d + o_h), len ? (int32_t*)(d + o_len) : nullptr,
+                                  flags, (double*)(d + o_qo), (int32_t*)(d + o_ns), (int32_t*)(d + o_st), nullptr);
+  if (rc == GMR_OK) {
+    if ((e = hipDeviceSynchronize()) != hipSuccess ||
+        (e = hipMemcpy(q_out, d + o_qo, b_qo, hipMemcpyDeviceToHost)) != hipSuccess ||
+        (e = hipMemcpy(nsolve, d + o_ns, b_ns, hipMemcpyDeviceToHost)) != hipSuccess ||
+        (e = hipMemcpy(status, d + o_st, b_st, hipMemcpyDeviceToHost)) != hipSuccess)
+      rc = fail(GMR_ERR_HIP, "kernel / D2H copy: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(d);
+  return rc;
+}
+
+// ---- post-hoc FK ----------------------------------------------------------------------------
+int gmr_fk_create(int nbody, const int32_t* parent, const float* local_t, const float* local_r,
+                  const int32_t* dof_idx, const double* axis, int ndof, gmr_fk_t** out) {
+  if (!out || !parent || !local_t || !local_r || !dof_idx || !axis) return fail(GMR_ERR_ARG, "null argument");
+  if (nbody < 1 || nbody > gmr::FK_MAX_BODIES) return fail(GMR_ERR_ARG, "nbody out of range");
+  if (ndof < 0) return fail(GMR_ERR_ARG, "ndof negative");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(GMR_ERR_NO_DEVICE, "no HIP device visible");
+  gmr_fk* k = new (std::nothrow) gmr_fk;
+  if (!k) return fail(GMR_ERR_ARG, "out of host memory");
+  memset(&k->tree, 0, sizeof k->tree);
+  gmr::FkTree& t = k->tree;
+  t.nbody = nbody; t.ndof = ndof;
+  int depth[gmr::FK_MAX_BODIES];
+  int maxd = 1;
+  if (parent[0] != -1) { delete k; return fail(GMR_ERR_ARG, "body 0 must be the root"); }
+  depth[0] = 0;
+  for (int b = 1; b < nbody; b++) {
+    if (parent[b] < 0 || parent[b] >= b) { delete k; return fail(GMR_ERR_ARG, "parent[%d] invalid", b); }
+    depth[b] = depth[parent[b]] + 1;
+    if (depth[b] + 1 > maxd) maxd = depth[b] + 1;
+  }
+  if (maxd > gmr::FK_MAX_DEPTH) { delete k; return fail(GMR_ERR_ARG, "tree too deep"); }
+  t.maxd = maxd;
+  for (int b = 0; b < nbody; b++) {
+    if (dof_idx[b] >= ndof) { delete k; return fail(GMR_ERR_ARG, "dof_idx[%d] out of range", b); }
+    t.dof_idx[b] = dof_idx[b];
+    t.depth[b] = (short)depth[b];
+    int c = b;
+    for (int d = depth[b]; d >= 0; d--) { t.chain[b * maxd + d] = (short)c; c = parent[c]; }
+    for (int a = 0; a < 3; a++) { t.local_t[3 * b + a] = local_t[3 * b + a]; t.axis[3 * b + a] = axis[3 * b + a]; }
+    for (int a = 0; a < 4; a++) t.local_r[4 * b + a] = local_r[4 * b + a];
+  }
+  hipError_t e;
+  if ((e = hipMalloc((void**)&k->d_tree, sizeof(gmr::FkTree))) != hipSuccess ||
+      (e = hipMemcpy(k->d_tree, &k->tree, sizeof(gmr::FkTree), hipMemcpyHostToDevice)) != hipSuccess) {
+    if (k->d_tree) (void)hipFree(k->d_tree);
+    delete k;
+    return fail(GMR_ERR_HIP, "gmr_fk_create: %s", hipGetErrorString(e));
+  }
+  *out = k;
+  return GMR_OK;
+}
+
+int gmr_fk_destroy(gmr_fk_t* k) {
+  if (!k) return GMR_OK;
+  (void)hipFree(k->d_tree);
+  if (k->d_min_part) (void)hipFree(k->d_min_part);
+  delete k;
+  return GMR_OK;
+}
+
+int gmr_fk_batch_dev(gmr_fk_t* k, int B, const float* d_root_pos, const float* d_root_rot, const float* d_dof,
+                     float* d_body_pos, float* d_body_rot, float* d_min_z, void* stream) {
+  if (!k) return fail(GMR_ERR_ARG, "null fk handle");
+  if (B < 0) return fail(GMR_ERR_ARG, "negative B");
+  if (B == 0) return GMR_OK;
+  if (!d_root_pos || !d_root_rot || !d_body_pos || (k->tree.ndof > 0 && !d_dof)) return fail(GMR_ERR_ARG, "null device buffer");
+  if (d_min_z) {
+    int blocks = gmr_fk_blocks(k->tree.nbody, B);
+    if (blocks > k->min_part_cap) {  // grows only; not graph-capturable on the first call of a size
+      if (k->d_min_part) (void)hipFree(k->d_min_part);
+      k->d_min_part = nullptr;
+      HIP_TRY(hipMalloc((void**)&k->d_min_part, (size_t)blocks * sizeof(float)));
+      k->min_part_cap = blocks;
+    }
+  }
+  HIP_TRY(gmr_launch_fk_batch(k->d_tree, k->tree.nbody, k->tree.maxd, B, d_root_pos, d_root_rot, d_dof, d_body_pos,
+                              d_body_rot, k->d_min_part, d_min_z, (hipStream_t)stream));
+  return GMR_OK;
+}
+
+int gmr_fk_batch(gmr_fk_t* k, int B, const float* root_pos, const float* root_rot, const float* dof, float* body_pos,
+                 float* body_rot, float* min_z) {
+  if (!k) return fail(GMR_ERR_ARG, "null fk handle");
+  if (B < 0) return fail(GMR_ERR_ARG, "negative B");
+  if (B == 0) return GMR_OK;
+  if (!root_pos || !root_rot || !body_pos) return fail(GMR_ERR_ARG, "null host buffer");
+  const size_t nb = k->tree.nbody, nd = k->tree.ndof;
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  size_t b_rp = (size_t)B * 12, b_rr = (size_t)B * 16, b_d = (size_t)B * nd * 4, b_bp = (size_t)B * nb * 12,
+         b_br = (size_t)B * nb * 16;
+  size_t o_rp = 0, o_rr = o_rp + up(b_rp), o_d = o_rr + up(b_rr), o_bp = o_d + up(b_d), o_br = o_bp + up(b_bp),
+         o_mz = o_br + up(b_br), total = o_mz + 256;
+  char* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, total));
+  int rc = GMR_OK;
+  hipError_t e;
+  if ((e = hipMemcpy(d + o_rp, root_pos, b_rp, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(d + o_rr, root_rot, b_rr, hipMemcpyHostToDevice)) != hipSuccess ||
+      (nd && (e = hipMemcpy(d + o_d, dof, b_d, hipMemcpyHostToDevice)) != hipSuccess))
+    rc = fail(GMR_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
+  if (rc == GMR_OK)
+    rc = gmr_fk_batch_dev(k, B, (float*)(d + o_rp), (float*)(d + o_rr), (float*)(d + o_d), (float*)(d + o_bp),
+                          body_rot ? (float*)(d + o_br) : nullptr, min_z ? (float*)(d + o_mz) : nullptr, nullptr);
+  if (rc == GMR_OK) {
+    if ((e = hipDeviceSynchronize()) != hipSuccess ||
+        (e = hipMemcpy(body_pos, d + o_bp, b_bp, hipMemcpyDeviceToHost)) != hipSuccess ||
+        (body_rot && (e = hipMemcpy(body_rot, d + o_br, b_br, hipMemcpyDeviceToHost)) != hipSuccess) ||
+        (min_z && (e = hipMemcpy(min_z, d + o_mz, 4, hipMemcpyDeviceToHost)) != hipSuccess))
+      rc = fail(GMR_ERR_HIP, "kernel / D2H copy: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(d);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,166 @@
+// gmr_device_math.h -- FP64 quaternion / SE(3) helpers for the gfx950 IK kernels.
+// Quaternions wxyz, tangent order [v; w].  Formulas follow SURVEY.md Appendix A (mink / MuJoCo
+// semantics, restated); small-angle series keep every coefficient accurate to ~1e-16.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gmr {
+
+struct d3 { double x, y, z; };
+struct d4 { double w, x, y, z; };
+
+__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ d3 operator*(double s, d3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ d3 cross(d3 a, d3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+__device__ __forceinline__ d4 qmul(d4 a, d4 b) {
+  return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z,
+          a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+          a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+__device__ __forceinline__ d4 qconj(d4 a) { return {a.w, -a.x, -a.y, -a.z}; }
+__device__ __forceinline__ d4 qnormalize(d4 a) {
+  double n2 = a.w * a.w + a.x * a.x + a.y * a.y + a.z * a.z;
+  double s = 1.0 / sqrt(n2);
+  return {a.w * s, a.x * s, a.y * s, a.z * s};
+}
+// rotate v by unit quaternion q: v + 2 w (u x v) + 2 u x (u x v)
+__device__ __forceinline__ d3 qrot(d4 q, d3 v) {
+  d3 u = {q.x, q.y, q.z};
+  d3 t = 2.0 * cross(u, v);
+  return v + q.w * t + cross(u, t);
+}
+// rotate v by the inverse of unit quaternion q
+__device__ __forceinline__ d3 qrot_inv(d4 q, d3 v) {
+  d3 u = {-q.x, -q.y, -q.z};
+  d3 t = 2.0 * cross(u, v);
+  return v + q.w * t + cross(u, t);
+}
+__device__ __forceinline__ d4 axis_angle(d3 axis, double angle) {
+  double s, c;
+  sincos(0.5 * angle, &s, &c);
+  return {c, axis.x * s, axis.y * s, axis.z * s};
+}
+
+// SO3 log of a unit quaternion (|w| <= pi), mink/jaxlie branch structure (App. A.5)
+__device__ __forceinline__ d3 so3_log(d4 q) {
+  double n2 = q.x * q.x + q.y * q.y + q.z * q.z;
+  double f;
+  if (n2 < 1e-10) {
+    f = 2.0 / q.w - 2.0 / 3.0 * n2 / (q.w * q.w * q.w);
+  } else {
+    double n = sqrt(n2);
+    if (fabs(q.w) < 1e-10) f = (q.w > 0.0 ? 1.0 : -1.0) * 3.14159265358979323846 / n;
+    else f = 2.0 * atan2(q.w < 0 ? -n : n, fabs(q.w)) / n;
+  }
+  return {f * q.x, f * q.y, f * q.z};
+}
+
+// coefficient a of K^2 in  I - K/2 + a K^2  (V^-1 of SE3.log and Jl^-1 of SO3 share it)
+__device__ __forceinline__ double vinv_coef(double t2) {
+  if (t2 < 1e-2)
+    return 1.0 / 12.0 + t2 * (1.0 / 720.0 + t2 * (1.0 / 30240.0 + t2 * (1.0 / 1209600.0 + t2 / 47900160.0)));
+  double t = sqrt(t2), h = 0.5 * t, s, c;
+  sincos(h, &s, &c);
+  return (1.0 - h * c / s) / t2;
+}
+
+// 3x3 row-major helpers
+struct m3 { double a[9]; };
+__device__ __forceinline__ m3 skew(d3 w) {
+  m3 K;
+  K.a[0] = 0; K.a[1] = -w.z; K.a[2] = w.y;
+  K.a[3] = w.z; K.a[4] = 0; K.a[5] = -w.x;
+  K.a[6] = -w.y; K.a[7] = w.x; K.a[8] = 0;
+  return K;
+}
+__device__ __forceinline__ m3 mmul(const m3& A, const m3& B) {
+  m3 C;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      C.a[3 * i + j] = A.a[3 * i] * B.a[j] + A.a[3 * i + 1] * B.a[3 + j] + A.a[3 * i + 2] * B.a[6 + j];
+  return C;
+}
+__device__ __forceinline__ d3 mvec(const m3& A, d3 v) {
+  return {A.a[0] * v.x + A.a[1] * v.y + A.a[2] * v.z, A.a[3] * v.x + A.a[4] * v.y + A.a[5] * v.z,
+          A.a[6] * v.x + A.a[7] * v.y + A.a[8] * v.z};
+}
+
+// e = log(T_wb^-1 T_wt) = [V^-1(w) p_bt ; w]
+__device__ __forceinline__ void se3_log_rel(d3 pb, d4 qb, d3 pt, d4 qt, double e[6]) {
+  d4 qbt = qmul(qconj(qb), qt);
+  d3 pbt = qrot_inv(qb, pt - pb);
+  d3 w = so3_log(qbt);
+  double t2 = dot(w, w);
+  double a = vinv_coef(t2);
+  // V^-1 p = p - 0.5 w x p + a w x (w x p)
+  d3 wp = cross(w, pbt);
+  d3 wwp = cross(w, wp);
+  d3 v = pbt - 0.5 * wp + a * wwp;
+  e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = w.x; e[4] = w.y; e[5] = w.z;
+}
+
+// Jl^-1(e) = [[A, B], [0, A]], B = -A Q A (Barfoot 7.86b); identity when |w|^2 < 1e-10 (mink)
+__device__ __forceinline__ void se3_jlinv(const double e[6], m3& A, m3& B) {
+  d3 rho = {e[0], e[1], e[2]}, w = {e[3], e[4], e[5]};
+  double t2 = dot(w, w);
+#pragma unroll
+  for (int i = 0; i < 9; i++) { A.a[i] = 0.0; B.a[i] = 0.0; }
+  A.a[0] = A.a[4] = A.a[8] = 1.0;
+  if (t2 < 1e-10) return;
+  double a = vinv_coef(t2);
+  m3 W = skew(w), V = skew(rho);
+  m3 W2 = mmul(W, W);
+#pragma unroll
+  for (int i = 0; i < 9; i++) A.a[i] += -0.5 * W.a[i] + a * W2.a[i];
+  double c1, c2, c3;
+  if (t2 < 1e-2) {
+    c1 = 1.0 / 6.0 - t2 / 120.0 + t2 * t2 / 5040.0 - t2 * t2 * t2 / 362880.0;
+    c2 = -1.0 / 24.0 + t2 / 720.0 - t2 * t2 / 40320.0 + t2 * t2 * t2 / 3628800.0;
+    c3 = -1.0 / 120.0 + t2 / 5040.0 - t2 * t2 / 362880.0 + t2 * t2 * t2 / 39916800.0;
+  } else {
+    double t = sqrt(t2), s, c;
+    sincos(t, &s, &c);
+    c1 = (t - s) / (t2 * t);
+    c2 = (1.0 - 0.5 * t2 - c) / (t2 * t2);
+    c3 = (t - s - t2 * t / 6.0) / (t2 * t2 * t);
+  }
+  double c4 = -0.5 * (c2 - 3.0 * c3);
+  m3 WV = mmul(W, V), VW = mmul(V, W);
+  m3 WVW = mmul(WV, W), WWV = mmul(W, WV), VWW = mmul(VW, W);
+  m3 WVWW = mmul(WVW, W), WWVW = mmul(W, WVW);
+  m3 Q;
+#pragma unroll
+  for (int i = 0; i < 9; i++)
+    Q.a[i] = 0.5 * V.a[i] + c1 * (WV.a[i] + VW.a[i] + WVW.a[i]) - c2 * (WWV.a[i] + VWW.a[i] - 3.0 * WVW.a[i]) +
+             c4 * (WVWW.a[i] + WWVW.a[i]);
+  m3 AQA = mmul(mmul(A, Q), A);
+#pragma unroll
+  for (int i = 0; i < 9; i++) B.a[i] = -AQA.a[i];
+}
+
+// wave64 butterfly reductions (deterministic, every lane gets the result)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+}  // namespace gmr

@@ -1,0 +1,20 @@
+// gmr_fk_tree.h -- device-side tree of the float32 post-hoc FK (reference KinematicsModel arrays).
+#pragma once
+#include <stdint.h>
+
+namespace gmr {
+
+constexpr int FK_MAX_BODIES = 64;
+constexpr int FK_MAX_DEPTH = 24;
+
+struct FkTree {
+  int nbody, ndof, maxd, _pad;
+  int32_t dof_idx[FK_MAX_BODIES];              // first dof of the body's joint or -1
+  short depth[FK_MAX_BODIES];
+  short chain[FK_MAX_BODIES * FK_MAX_DEPTH];   // [nbody][maxd] packed with stride maxd
+  float local_t[FK_MAX_BODIES * 3];
+  float local_r[FK_MAX_BODIES * 4];            // xyzw, un-normalised (kinematics_model.py:119-123)
+  double axis[FK_MAX_BODIES * 3];              // float64 hinge axis (kinematics_model.py:133-134)
+};
+
+}  // namespace gmr

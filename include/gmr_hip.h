@@ -1,0 +1,116 @@
+/*
+ * gmr_hip.h -- C-ABI of libgmrhip.so: the MI355X (gfx950) implementation of GMR's retargeting
+ * hot path.  Plain C, plain pointers and sizes, no torch / no C++ types: this is exactly what a
+ * ctypes (or cffi / cgo / JNI) binding in the reference would bind.  INTEGRATION.md shows the
+ * reference-side stub.
+ *
+ * Conventions: every function returns 0 on success and a negative code on error
+ * (gmr_last_error() returns a thread-local message); handles are immutable after creation, so
+ * batch calls on different HIP streams are re-entrant.  "dev" entry points take device pointers
+ * and a hipStream_t (as void*; NULL = the default stream) and never synchronise; the entry points
+ * without the suffix take host pointers, copy, launch and synchronise.
+ *
+ * Row IDs (H1..H10) refer to SURVEY.md section 8(a).
+ */
+#ifndef GMR_HIP_H
+#define GMR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "gmr_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMR_OK 0
+#define GMR_ERR_ARG (-1)     /* bad argument / bad blob                                   */
+#define GMR_ERR_HIP (-2)     /* a HIP runtime call failed                                  */
+#define GMR_ERR_NO_DEVICE (-3)
+
+/* retarget flags */
+#define GMR_FLAG_OFFSET_TO_GROUND 1 /* retarget(human_data, offset_to_ground=True), motion_retarget.py:139 */
+
+/* per-stream status written by the IK kernel */
+#define GMR_STATUS_OK 0
+#define GMR_STATUS_QP_FAILED (-1)   /* Cholesky breakdown / non-finite input; mink would raise (section 8b) */
+#define GMR_STATUS_QP_MAXITER (-2)  /* active-set iteration cap hit                                         */
+
+typedef struct gmr_solver gmr_solver_t; /* device-resident (model, task set)                    */
+typedef struct gmr_fk gmr_fk_t;         /* device-resident KinematicsModel tree (float32 path)  */
+
+/* ---- library / device ------------------------------------------------------------------- */
+const char* gmr_last_error(void);
+const char* gmr_backend_info(void);     /* "hip:gfx950 ..." ; replaces nothing, diagnostic      */
+int gmr_device_count(void);
+int gmr_set_device(int device);
+size_t gmr_sizeof_model(void);          /* ABI check against the Python-side struct layouts      */
+size_t gmr_sizeof_taskset(void);
+
+/* ---- device memory / streams / events (so that the Python host needs no torch) ----------- */
+int gmr_malloc(void** ptr, size_t bytes);
+int gmr_free(void* ptr);
+int gmr_memset(void* ptr, int value, size_t bytes, void* stream);
+int gmr_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int gmr_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int gmr_stream_create(void** stream);
+int gmr_stream_destroy(void* stream);
+int gmr_stream_sync(void* stream);      /* NULL = device synchronize                             */
+int gmr_event_create(void** event);
+int gmr_event_destroy(void* event);
+int gmr_event_record(void* event, void* stream);
+int gmr_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop`          */
+
+/* ---- H1: solver state ------------------------------------------------------------------- */
+/* Replaces GeneralMotionRetargeting.__init__ + setup_retarget_configuration
+ * (motion_retarget.py:13-114): uploads the packed robot model and task set.  The blobs are the
+ * same bytes rank 0 broadcasts to its peers. */
+int gmr_solver_create(const gmr_model_t* model, const gmr_taskset_t* taskset, gmr_solver_t** out);
+int gmr_solver_destroy(gmr_solver_t* solver);
+int gmr_solver_dims(const gmr_solver_t* solver, int* nq, int* nv, int* nhuman);
+
+/* ---- H2-H7: the retargeting loop ---------------------------------------------------------- */
+/* Replaces the caller loop `for frame in frames: qpos = retargeter.retarget(frame)`
+ * (scripts/smplx_to_robot_dataset.py:85-87) around GeneralMotionRetargeting.retarget
+ * (motion_retarget.py:139-185) for S independent streams of up to T frames each, with the time
+ * loop on the device (frames of one stream are sequentially dependent: warm start, :75).
+ *
+ *   q0      f64 [S][nq]            configuration before the first frame (qpos0 for a fresh object)
+ *   human   f64 [S][T][nhuman][7]  raw human_data of the bodies of the scale table, packed order
+ *                                  (pos xyz, quat wxyz); a body absent from the caller's dict is
+ *                                  encoded with pos[0] = NaN
+ *   len     i32 [S] or NULL        frames of stream s (<= T); NULL = all T
+ *   q_out   f64 [S][T][nq]         qpos after each frame (what retarget() returns, :185)
+ *   nsolve  i32 [S][T][2]          solve_ik calls per stage (1 + loop iterations, :147-161)
+ *   status  i32 [S]                GMR_STATUS_*
+ */
+int gmr_retarget_streams_dev(gmr_solver_t* solver, int S, int T, const double* d_q0, const double* d_human,
+                             const int32_t* d_len, int flags, double* d_q_out, int32_t* d_nsolve,
+                             int32_t* d_status, void* stream);
+int gmr_retarget_streams(gmr_solver_t* solver, int S, int T, const double* q0, const double* human,
+                         const int32_t* len, int flags, double* q_out, int32_t* nsolve, int32_t* status);
+/* LDS bytes per stream of the IK kernel for this solver (occupancy reporting). */
+int gmr_retarget_lds_bytes(const gmr_solver_t* solver);
+
+/* ---- H8-H9: post-hoc batched FK (float32) ------------------------------------------------- */
+/* Replaces KinematicsModel(xml, device="cuda:0") + forward_kinematics
+ * (kinematics_model.py:69-170, 213-246), i.e. ~2.6k ATen launches per call -> one kernel.
+ * Tree arrays are those of the reference's own XML reader (mjcf.parse_kinematics_tree):
+ * local_r xyzw un-normalised, axis f64 per body (zeros where dof_idx < 0). */
+int gmr_fk_create(int nbody, const int32_t* parent, const float* local_t, const float* local_r,
+                  const int32_t* dof_idx, const double* axis, int ndof, gmr_fk_t** out);
+int gmr_fk_destroy(gmr_fk_t* fk);
+/*   root_pos f32 [B][3], root_rot f32 [B][4] xyzw, dof f32 [B][ndof]
+ *   body_pos f32 [B][nbody][3], body_rot f32 [B][nbody][4] (may be NULL)
+ *   min_z    f32 [1] (may be NULL): min over all frames and bodies of body_pos z -- the reduction
+ *            of the dataset scripts' height adjustment (smplx_to_robot_dataset.py:118-126)        */
+int gmr_fk_batch_dev(gmr_fk_t* fk, int B, const float* d_root_pos, const float* d_root_rot, const float* d_dof,
+                     float* d_body_pos, float* d_body_rot, float* d_min_z, void* stream);
+int gmr_fk_batch(gmr_fk_t* fk, int B, const float* root_pos, const float* root_rot, const float* dof,
+                 float* body_pos, float* body_rot, float* min_z);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMR_HIP_H */

@@ -1,0 +1,142 @@
+"""ctypes wrapper around oracle/libgmr_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (general_motion_retargeting_amd) never does.  Parity status of each function is
+stated in the header of gmr_oracle.c.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libgmr_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "gmr_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libgmr_oracle.so"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_solve_box_qp.restype = C.c_int
+        _lib.orc_retarget_frame.restype = C.c_int
+        _lib.orc_stage_error.restype = C.c_double
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def check_abi(model_blob: np.ndarray, taskset_blob: np.ndarray) -> None:
+    L = lib()
+    assert L.orc_sizeof_model() == model_blob.dtype.itemsize, (L.orc_sizeof_model(), model_blob.dtype.itemsize)
+    assert L.orc_sizeof_taskset() == taskset_blob.dtype.itemsize
+
+
+def preprocess(ts, human, offset_to_ground=False):
+    human = _c(human, np.float64)
+    out = np.empty_like(human)
+    flat = human.reshape(-1, human.shape[-2], 7)
+    o = out.reshape(flat.shape)
+    for i in range(flat.shape[0]):
+        lib().orc_preprocess(_p(ts), _p(flat[i]), int(offset_to_ground), _p(o[i]))
+    return out
+
+
+def fk(model, q):
+    nb = int(model["nbody"][0])
+    q = _c(q, np.float64)
+    xpos = np.empty((nb, 3))
+    xquat = np.empty((nb, 4))
+    lib().orc_fk_flat(_p(model), _p(q), _p(xpos), _p(xquat))
+    return xpos, xquat
+
+
+def so3_log(q):
+    w = np.empty(3)
+    lib().orc_so3_log(_p(_c(q, np.float64)), _p(w))
+    return w
+
+
+def se3_log_rel(pb, qb, Rb, pt, qt):
+    e = np.empty(6)
+    lib().orc_se3_log_rel(_p(_c(pb, np.float64)), _p(_c(qb, np.float64)), _p(_c(Rb, np.float64)),
+                          _p(_c(pt, np.float64)), _p(_c(qt, np.float64)), _p(e))
+    return e
+
+
+def se3_jlinv(e):
+    A = np.empty((3, 3))
+    B = np.empty((3, 3))
+    lib().orc_se3_jlinv(_p(_c(e, np.float64)), _p(A), _p(B))
+    J = np.zeros((6, 6))
+    J[:3, :3] = A
+    J[:3, 3:] = B
+    J[3:, 3:] = A
+    return J
+
+
+def solve_box_qp(H, c, lo, hi):
+    n = H.shape[0]
+    x = np.empty(n)
+    rc = lib().orc_solve_box_qp(n, _p(_c(H, np.float64)), _p(_c(c, np.float64)), _p(_c(lo, np.float64)),
+                                _p(_c(hi, np.float64)), _p(x))
+    return x, rc
+
+
+def retarget_frame(model, ts, q, human, offset_to_ground=False):
+    """One retarget() call: returns (q_next, nsolve[2], targets[nhuman,7], rc)."""
+    q = _c(q, np.float64).copy()
+    nh = int(ts["nhuman"][0])
+    ns = np.zeros(2, dtype=np.int32)
+    tgt = np.empty((nh, 7))
+    rc = lib().orc_retarget_frame(_p(model), _p(ts), _p(q), _p(_c(human, np.float64)), int(offset_to_ground),
+                                  _p(ns), _p(tgt))
+    return q, ns, tgt, rc
+
+
+def retarget_streams(model, ts, q0, human, offset_to_ground=False, nthreads=1):
+    """q0[S,nq], human[S,T,nh,7] -> q_out[S,T,nq], nsolve[S,T,2], status[S]."""
+    human = _c(human, np.float64)
+    S, T = human.shape[0], human.shape[1]
+    nq = int(model["nq"][0])
+    q0 = _c(q0, np.float64).reshape(S, nq)
+    q_out = np.empty((S, T, nq))
+    ns = np.zeros((S, T, 2), dtype=np.int32)
+    st = np.zeros(S, dtype=np.int32)
+    lib().orc_retarget_streams(_p(model), _p(ts), S, T, _p(q0), _p(human), int(offset_to_ground), _p(q_out),
+                               _p(ns), _p(st), int(nthreads))
+    return q_out, ns, st
+
+
+def fk_f32(tree, root_pos, root_rot, dof):
+    """KinematicsModel.forward_kinematics semantics; tree = dict from mjcf.parse_kinematics_tree."""
+    nb = len(tree["parent"])
+    root_pos = _c(root_pos, np.float32)
+    root_rot = _c(root_rot, np.float32)
+    dof = _c(dof, np.float32)
+    B = root_pos.shape[0]
+    nd = dof.shape[1]
+    bp = np.empty((B, nb, 3), dtype=np.float32)
+    br = np.empty((B, nb, 4), dtype=np.float32)
+    lib().orc_fk_f32(nb, _p(_c(tree["parent"], np.int32)), _p(_c(tree["local_translation"], np.float32)),
+                     _p(_c(tree["local_rotation"], np.float32)), _p(_c(tree["dof_idx"], np.int32)),
+                     _p(_c(tree["axis"], np.float64)), nd, B, _p(root_pos), _p(root_rot), _p(dof), _p(bp), _p(br))
+    return bp, br

@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures tests/golden/*.npz by RUNNING the reference's own Python where it
+is importable in the build container:
+
+* G-PRE  -- ``GeneralMotionRetargeting.__init__`` / ``setup_retarget_configuration`` /
+  ``update_targets`` (reference ``general_motion_retargeting/motion_retarget.py:13-136,203-270``)
+  for every (source, robot) ik_config: seeded random ``human_data`` in, ``scaled_human_data`` and
+  the poses handed to ``task.set_target`` out.  ``mink`` and ``mujoco`` are not installed; the
+  preprocessing never touches them, so inert placeholder modules are registered under those names
+  (they only record constructor arguments).  This pins rows H1-H3.
+* G-FK   -- ``KinematicsModel`` (reference ``general_motion_retargeting/kinematics_model.py``) on
+  CPU torch for the 7 robots it can parse: parsed tree arrays and ``forward_kinematics`` outputs
+  for seeded random inputs.  This pins rows H8-H9.
+
+Nothing here pins rows H4-H7 (the mink/MuJoCo/DAQP numerics): "parity unpinned", see DESIGN.md.
+
+Only numbers and names are stored (``np.savez_compressed``; loadable with allow_pickle=False).
+
+    python tests/golden/make_golden.py            # needs /root/reference
+"""
+import importlib
+import os
+import pathlib
+import sys
+import types
+
+import numpy as np
+
+REF = pathlib.Path(os.environ.get("GMR_REFERENCE_ROOT", "/root/reference"))
+OUT = pathlib.Path(__file__).resolve().parent
+
+
+# --------------------------------------------------------------------------- #
+# inert placeholders for the two uninstalled third-party packages
+# --------------------------------------------------------------------------- #
+class _Rec:
+    def __init__(self, *a, **k):
+        self.args, self.kwargs = a, k
+
+
+def _install_placeholders():
+    mink = types.ModuleType("mink")
+
+    class Configuration(_Rec):
+        pass
+
+    class FrameTask(_Rec):
+        target = None
+
+        def set_target(self, t):
+            self.target = t
+
+    class SO3(_Rec):
+        pass
+
+    class SE3(_Rec):
+        @classmethod
+        def from_rotation_and_translation(cls, rot, pos):
+            return cls(rot, pos)
+
+    mink.Configuration, mink.FrameTask, mink.SO3, mink.SE3 = Configuration, FrameTask, SO3, SE3
+    sys.modules["mink"] = mink
+
+    mujoco = types.ModuleType("mujoco")
+
+    class MjModel(_Rec):
+        @classmethod
+        def from_xml_path(cls, path):
+            return cls(path)
+
+    mujoco.MjModel = MjModel
+    sys.modules["mujoco"] = mujoco
+
+
+def _load_ref_module(name):
+    """Import general_motion_retargeting.<name> without running the package __init__."""
+    pkg_name = "general_motion_retargeting"
+    if pkg_name not in sys.modules:
+        pkg = types.ModuleType(pkg_name)
+        pkg.__path__ = [str(REF / pkg_name)]
+        sys.modules[pkg_name] = pkg
+    return importlib.import_module(f"{pkg_name}.{name}")
+
+
+def _random_human(rng, names, extra=("head", "jaw_extra")):
+    data = {}
+    for n in list(names) + list(extra):
+        pos = rng.normal(0.0, 0.6, size=3) + np.array([0.0, 0.0, 0.9])
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        q *= 1.0 + 1e-3 * rng.normal()          # slightly de-normalised, like real loader output
+        data[n] = (pos, q)
+    return data
+
+
+def make_pre():
+    _install_placeholders()
+    params = _load_ref_module("params")
+    mr = _load_ref_module("motion_retarget")
+    out = {}
+    idx = 0
+    for src, tbl in params.IK_CONFIG_DICT.items():
+        for robot in tbl:
+            for height in (None, 1.62):
+                rng = np.random.default_rng(1000 + idx)
+                idx += 1
+                g = mr.GeneralMotionRetargeting(src, robot, actual_human_height=height)
+                names = list(g.human_scale_table.keys())
+                tag = f"{src}__{robot}__{'none' if height is None else 'h162'}"
+                for ground in (False, True):
+                    hd = _random_human(rng, names)
+                    raw = np.array([np.concatenate([hd[n][0], hd[n][1]]) for n in names])
+                    try:
+                        g.update_targets(hd, offset_to_ground=ground)
+                    except KeyError as e:      # some configs name scale bodies without table-1 entry
+                        out[f"{tag}__g{int(ground)}__keyerror"] = np.array(str(e))
+                        continue
+                    sc = g.scaled_human_data
+                    arr = np.array([np.concatenate([sc[n][0], sc[n][1]]) for n in names])
+                    out[f"{tag}__g{int(ground)}__names"] = np.array(names)
+                    out[f"{tag}__g{int(ground)}__raw"] = raw
+                    out[f"{tag}__g{int(ground)}__scaled"] = arr
+                    for s, tasks in ((1, g.tasks1), (2, g.tasks2)):
+                        use = g.use_ik_match_table1 if s == 1 else g.use_ik_match_table2
+                        if not use:
+                            continue
+                        tg = []
+                        for t in tasks:
+                            se3 = t.target
+                            rot = np.asarray(se3.args[0].args[0], dtype=np.float64)
+                            pos = np.asarray(se3.args[1], dtype=np.float64)
+                            tg.append(np.concatenate([pos, rot]))
+                        out[f"{tag}__g{int(ground)}__targets{s}"] = np.array(tg)
+                        out[f"{tag}__g{int(ground)}__frames{s}"] = np.array([t.kwargs["frame_name"] for t in tasks])
+                        out[f"{tag}__g{int(ground)}__costs{s}"] = np.array(
+                            [[t.kwargs["position_cost"], t.kwargs["orientation_cost"]] for t in tasks], dtype=np.float64)
+    np.savez_compressed(OUT / "g_pre.npz", **out)
+    print("g_pre.npz:", len(out), "arrays")
+
+
+def make_fk():
+    import torch
+    params = _load_ref_module("params")
+    km = _load_ref_module("kinematics_model")
+    out = {}
+    for i, (robot, xml) in enumerate(params.ROBOT_XML_DICT.items()):
+        try:
+            model = km.KinematicsModel(str(xml), device="cpu")
+        except AssertionError as e:
+            out[f"{robot}__error"] = np.array(str(e))
+            print("  ", robot, "-> AssertionError:", e)
+            continue
+        rng = np.random.default_rng(2000 + i)
+        B = 24
+        lo, hi = model.get_dof_limits()
+        lo, hi = lo.numpy(), hi.numpy()
+        dof = (lo + (hi - lo) * rng.uniform(size=(B, model.num_dof))).astype(np.float32)
+        root_pos = rng.normal(size=(B, 3)).astype(np.float32)
+        rq = rng.normal(size=(B, 4))
+        root_rot = (rq / np.linalg.norm(rq, axis=1, keepdims=True)).astype(np.float32)   # xyzw
+        bp, br = model.forward_kinematics(torch.from_numpy(root_pos), torch.from_numpy(root_rot), torch.from_numpy(dof))
+        out[f"{robot}__body_names"] = np.array(model.body_names)
+        out[f"{robot}__parent"] = model.parent_indices.numpy().astype(np.int32)
+        out[f"{robot}__local_translation"] = model._local_translation.numpy()
+        out[f"{robot}__local_rotation"] = model._local_rotation.numpy()
+        out[f"{robot}__dof_idx"] = np.array(model.joint_dof_idx, dtype=np.int32)
+        out[f"{robot}__lower"] = lo
+        out[f"{robot}__upper"] = hi
+        out[f"{robot}__dof"] = dof
+        out[f"{robot}__root_pos"] = root_pos
+        out[f"{robot}__root_rot"] = root_rot
+        out[f"{robot}__body_pos"] = bp.numpy()
+        out[f"{robot}__body_rot"] = br.numpy()
+        # identity-root call, as the dataset scripts do for local_body_pos (smplx_to_robot_dataset.py:106-112)
+        z = torch.zeros((B, 3))
+        idq = torch.zeros((B, 4)); idq[:, -1] = 1.0
+        lbp, _ = model.forward_kinematics(z, idq, torch.from_numpy(dof))
+        out[f"{robot}__local_body_pos"] = lbp.numpy()
+    np.savez_compressed(OUT / "g_fk.npz", **out)
+    print("g_fk.npz:", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    make_pre()
+    make_fk()
