@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <new>
+#include <vector>
 
 #include "../../include/gmr_hip.h"
 #include "gmr_fk_tree.h"
@@ -16,10 +17,11 @@ static_assert(sizeof(gmr_taskset_t) % 8 == 0, "gmr_taskset_t must be 8-byte size
 static_assert(offsetof(gmr_model_t, timestep) % 8 == 0, "double block of gmr_model_t misaligned");
 static_assert(offsetof(gmr_taskset_t, damping) % 8 == 0, "double block of gmr_taskset_t misaligned");
 
-extern "C" hipError_t gmr_launch_ik_streams(const gmr_model_t*, const gmr_taskset_t*, const gmr::IkLayout*, int, int,
-                                            const double*, const double*, const int32_t*, int, double*, int32_t*,
-                                            int32_t*, hipStream_t);
-extern "C" hipError_t gmr_ik_set_max_smem(int bytes);
+extern "C" hipError_t gmr_launch_ik_streams(const gmr_model_t*, const gmr_taskset_t*, const uint32_t*,
+                                            const gmr::IkLayout*, int, int, const double*, const double*,
+                                            const int32_t*, int, double*, int32_t*, int32_t*, hipStream_t,
+                                            unsigned long long*);
+extern "C" hipError_t gmr_ik_set_max_smem(int nvp, int bytes);
 extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree*, int, int, int, const float*, const float*, const float*,
                                           float*, float*, float*, float*, hipStream_t);
 extern "C" int gmr_fk_blocks(int nbody, int B);
@@ -46,6 +48,7 @@ struct gmr_solver {
   gmr::IkLayout layout;
   gmr_model_t* d_model = nullptr;
   gmr_taskset_t* d_ts = nullptr;
+  uint32_t* d_sched = nullptr;   // static H-assembly schedule (gmr_ik_layout.h)
 };
 
 struct gmr_fk {
@@ -185,16 +188,26 @@ int gmr_solver_create(const gmr_model_t* model, const gmr_taskset_t* taskset, gm
   if (!s) return fail(GMR_ERR_ARG, "out of host memory");
   s->model = *model;
   s->ts = *taskset;
-  s->layout = gmr::make_ik_layout(s->model, s->ts);
+  if (gmr::ik_padded_nv(s->model.nv) < 0) { delete s; return fail(GMR_ERR_ARG, "nv = %d > 36 is not supported", s->model.nv); }
+  gmr::IkSchedule sch = gmr::make_ik_schedule(s->model, s->ts);
+  s->layout = gmr::make_ik_layout(s->model, s->ts, sch);
   if (s->layout.smem_bytes > 160 * 1024) { delete s; return fail(GMR_ERR_ARG, "robot too large for LDS"); }
+  std::vector<uint32_t> words((size_t)s->layout.n_word, 0u);
+  for (int st = 0; st < 2; st++) {
+    for (size_t i = 0; i < sch.items[st].size(); i++) words[s->layout.w_items[st] + i] = sch.items[st][i];
+    for (int l = 0; l < 65; l++) words[s->layout.w_istart[st] + l] = (uint32_t)sch.istart[st][l];
+  }
   hipError_t e;
   if ((e = hipMalloc((void**)&s->d_model, sizeof(gmr_model_t))) != hipSuccess ||
       (e = hipMalloc((void**)&s->d_ts, sizeof(gmr_taskset_t))) != hipSuccess ||
+      (e = hipMalloc((void**)&s->d_sched, words.size() * sizeof(uint32_t) + 8)) != hipSuccess ||
       (e = hipMemcpy(s->d_model, &s->model, sizeof(gmr_model_t), hipMemcpyHostToDevice)) != hipSuccess ||
       (e = hipMemcpy(s->d_ts, &s->ts, sizeof(gmr_taskset_t), hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = gmr_ik_set_max_smem(s->layout.smem_bytes)) != hipSuccess) {
+      (e = hipMemcpy(s->d_sched, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = gmr_ik_set_max_smem(s->layout.nvp, s->layout.smem_bytes)) != hipSuccess) {
     if (s->d_model) (void)hipFree(s->d_model);
     if (s->d_ts) (void)hipFree(s->d_ts);
+    if (s->d_sched) (void)hipFree(s->d_sched);
     delete s;
     return fail(GMR_ERR_HIP, "gmr_solver_create: %s", hipGetErrorString(e));
   }
@@ -206,6 +219,7 @@ int gmr_solver_destroy(gmr_solver_t* s) {
   if (!s) return GMR_OK;
   (void)hipFree(s->d_model);
   (void)hipFree(s->d_ts);
+  (void)hipFree(s->d_sched);
   delete s;
   return GMR_OK;
 }
@@ -227,10 +241,20 @@ int gmr_retarget_streams_dev(gmr_solver_t* s, int S, int T, const double* d_q0, 
   if (S < 0 || T < 0) return fail(GMR_ERR_ARG, "negative S/T");
   if (S == 0 || T == 0) return GMR_OK;
   if (!d_q0 || !d_human || !d_q_out || !d_nsolve || !d_status) return fail(GMR_ERR_ARG, "null device buffer");
-  HIP_TRY(gmr_launch_ik_streams(s->d_model, s->d_ts, &s->layout, S, T, d_q0, d_human, d_len, flags, d_q_out,
-                                d_nsolve, d_status, (hipStream_t)stream));
+  HIP_TRY(gmr_launch_ik_streams(s->d_model, s->d_ts, s->d_sched, &s->layout, S, T, d_q0, d_human, d_len, flags,
+                                d_q_out, d_nsolve, d_status, (hipStream_t)stream, nullptr));
   return GMR_OK;
 }
+
+#ifdef GMR_IK_PROFILE
+// diagnostic builds only (tools/phase_profile.py): per-stream phase cycle counters
+int gmr_retarget_streams_prof(gmr_solver_t* s, int S, int T, const double* d_q0, const double* d_human, int flags,
+                              double* d_q_out, int32_t* d_nsolve, int32_t* d_status, unsigned long long* d_prof) {
+  HIP_TRY(gmr_launch_ik_streams(s->d_model, s->d_ts, s->d_sched, &s->layout, S, T, d_q0, d_human, nullptr, flags,
+                                d_q_out, d_nsolve, d_status, nullptr, d_prof));
+  return GMR_OK;
+}
+#endif
 
 int gmr_retarget_streams(gmr_solver_t* s, int S, int T, const double* q0, const double* human, const int32_t* len,
                          int flags, double* q_out, int32_t* nsolve, int32_t* status) {

@@ -3,21 +3,34 @@
 // One 64-lane wavefront per motion stream (clip / robot instance).  Frames of a stream are
 // sequentially dependent (the configuration is warm-started from the previous frame, reference
 // motion_retarget.py:75,139-185), so the time loop runs on the device and the parallel width of a
-// launch is the number of streams.  Everything a stream touches between two frames lives in LDS:
+// launch is the number of streams.  Everything a stream touches between two frames lives in LDS or
+// in registers:
 //
-//   constants  joint-local transforms (body pos/quat, hinge axes), limits, task tables
-//   state      q, FK (xpos/xquat/world hinge axes), targets, task residuals e_k, -Jl^-1(e_k),
-//              the weighted per-(task,dof) Jacobian columns, H, its working copy, c, bounds
+//   LDS constants  joint-local transforms (body pos/quat, hinge axes), limits, task tables,
+//                  the static H-assembly schedule
+//   LDS state      q, FK ping-pong (pos, quat per body), world hinge axes, targets, residuals e_k,
+//                  -Jl^-1(e_k), weighted per-(task,dof) Jacobian columns, H, c, bounds
+//   registers      the working copy of H during the factorisation: lane i holds row i
 //
 // Per frame only nhuman*7 doubles are read from HBM (coalesced, contiguous) and nq doubles are
 // written, i.e. 1 072 B/frame for G1: the kernel is bound by the dependent FP64 chain, not by HBM
 // ("Roofline").
 //
-// Lane mapping: FK -> lane = body (each lane walks its own root->body chain in registers, no
-// level-by-level LDS hand-off); residuals / Jl^-1 -> lane = task; Jacobian columns -> lane = (task,
-// ancestor dof) pair; H accumulation -> lane = (column a, column b) of the current task's block
-// (the Jacobian of a task is non-zero only on the dofs of its root->frame path, so J^T W^2 J is
-// accumulated block-sparse: 11k instead of 103k multiply-adds for G1); QP -> lane = row.
+// Lane mapping per phase
+//   FK          lane = body; log2(depth) rounds of pointer jumping over the kinematic tree
+//               (transform composition is associative), ping-pong buffers in LDS
+//   residuals   lane = task: e_k = log(T_wb^-1 T_wt); wave butterfly for |e|
+//   Jl^-1       lane = task
+//   Jacobian    lane = (task, ancestor dof) pair: weighted column W_k (-Jl^-1) J_body[:, d]
+//   H           lane = owner of a set of H entries (static LPT schedule, gmr_ik_layout.h): the
+//               Jacobian of a task is non-zero only on its root->frame path, so H is assembled
+//               block-sparse (6k instead of 103k multiply-adds for G1), one store per entry
+//   QP          lane = row of H.  Dense Cholesky with the row in registers, fully unrolled:
+//               pivot column broadcast through v_readlane (SGPR operands), no LDS in the
+//               factorisation; L^T for the back substitution through one LDS transpose.
+//               Box constraints: block principal pivoting (all violated bounds / multipliers are
+//               exchanged at once, Murty's single exchange as the finite-termination fallback),
+//               warm-started from the previous solve's active set.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -30,55 +43,93 @@ namespace gmr {
 
 #define WSYNC() __syncthreads()
 
-struct IkSmem {
-  double* base;
-  const IkLayout* L;
-  __device__ __forceinline__ double* d(int off) const { return base + off; }
+// Diagnostic phase timer (GMR_IK_PROFILE builds only; never in the shipped kernel): s_memtime
+// stamps accumulated per phase, written to a buffer no other code reads.
+enum { PH_PRE, PH_FK, PH_ERR, PH_JLOG, PH_PAIRS, PH_CVEC, PH_HACC, PH_KBUILD, PH_CHOL, PH_SUBST, PH_RATIO,
+       PH_MULT, PH_INTEG, PH_IO, PH_NFACT, PH_NSOLVE, PH_TICKS, PH_REALTIME, PH_COUNT };
+#ifdef GMR_IK_PROFILE
+struct Prof {
+  unsigned long long acc[PH_COUNT];
+  unsigned long long t0;
+  __device__ __forceinline__ void begin() { t0 = __builtin_amdgcn_s_memtime(); }
+  __device__ __forceinline__ void end(int ph) { acc[ph] += __builtin_amdgcn_s_memtime() - t0; }
+  __device__ __forceinline__ void count(int ph) { acc[ph] += 1; }
 };
+#define PROF_BEGIN(p) (p).begin()
+#define PROF_END(p, ph) (p).end(ph)
+#define PROF_COUNT(p, ph) (p).count(ph)
+#else
+struct Prof {};
+#define PROF_BEGIN(p)
+#define PROF_END(p, ph)
+#define PROF_COUNT(p, ph)
+#endif
+
+// value of lane `src` (wave-uniform index) as a scalar operand
+__device__ __forceinline__ double readlane_d(double v, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double dot6(const double* a, const double* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
 
 // ---------------------------------------------------------------------------------------------
-// FK: mj_kinematics semantics (App. A.3).  lane b < nb.
+// FK: mj_kinematics semantics (App. A.3), evaluated by pointer jumping.  lane b < nb.
+// Result: (pos, quat) per body at sm[L.xa + 7 b], world hinge axes at sm[L.xaxis + 3 b].
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fk_wave(const IkLayout& L, double* sm, const short* chain, const short* depth,
-                                        const short* body_hinge, int lane) {
+__device__ __forceinline__ void fk_wave(const IkLayout& L, double* sm, const short* hop, const short* depth,
+                                        const short* body_hinge, int lane, Prof& pr) {
+  PROF_BEGIN(pr);
   const int nb = L.nb;
   double* q = sm + L.q;
-  double* lq = sm + L.lq;
-  // step A: local quaternion of every body (body quat * hinge rotation); body 0: normalised root quat
+  d3 pos = {0, 0, 0};
+  d4 quat = {1, 0, 0, 0};
+  int dep = 0;
+  // round 0 input: transform of every body relative to its parent (body 0: world pose)
   if (lane < nb) {
-    d4 r;
+    dep = depth[lane];
     if (lane == 0) {
-      r = qnormalize(d4{q[3], q[4], q[5], q[6]});
-      q[3] = r.w; q[4] = r.x; q[5] = r.y; q[6] = r.z;
+      quat = qnormalize(d4{q[3], q[4], q[5], q[6]});
+      q[3] = quat.w; q[4] = quat.x; q[5] = quat.y; q[6] = quat.z;
+      pos = d3{q[0], q[1], q[2]};
     } else {
       const double* bq = sm + L.body_quat + 4 * lane;
-      r = d4{bq[0], bq[1], bq[2], bq[3]};
+      const double* bp = sm + L.body_pos + 3 * lane;
+      quat = d4{bq[0], bq[1], bq[2], bq[3]};
+      pos = d3{bp[0], bp[1], bp[2]};
       int h = body_hinge[lane];
       if (h >= 0) {
         const double* ax = sm + L.axis + 3 * lane;
         double th = q[7 + h];
-        if (th != 0.0) r = qmul(r, axis_angle(d3{ax[0], ax[1], ax[2]}, th));
+        if (th != 0.0) quat = qmul(quat, axis_angle(d3{ax[0], ax[1], ax[2]}, th));
       }
     }
-    lq[4 * lane + 0] = r.w; lq[4 * lane + 1] = r.x; lq[4 * lane + 2] = r.y; lq[4 * lane + 3] = r.z;
   }
-  WSYNC();
-  // step B: every lane walks root -> its body
-  if (lane < nb) {
-    d3 pos = {q[0], q[1], q[2]};
-    d4 quat = {lq[0], lq[1], lq[2], lq[3]};
-    const int dep = depth[lane];
-    const short* ch = chain + lane * L.maxd;
-    for (int dd = 1; dd <= dep; dd++) {
-      int c = ch[dd];
-      const double* bp = sm + L.body_pos + 3 * c;
-      pos = pos + qrot(quat, d3{bp[0], bp[1], bp[2]});
-      quat = qnormalize(qmul(quat, d4{lq[4 * c], lq[4 * c + 1], lq[4 * c + 2], lq[4 * c + 3]}));
+  // after round r a body's transform is relative to its ancestor 2^(r+1) levels up (or the world);
+  // rounds alternate between the two buffers so that one barrier per round suffices
+  for (int r = 0; r < L.nhop; r++) {
+    double* wb = sm + ((r & 1) ? L.xa : L.xb);
+    if (lane < nb) {
+      double* o = wb + 7 * lane;
+      o[0] = pos.x; o[1] = pos.y; o[2] = pos.z; o[3] = quat.w; o[4] = quat.x; o[5] = quat.y; o[6] = quat.z;
     }
-    double* xp = sm + L.xpos + 3 * lane;
-    double* xq = sm + L.xquat + 4 * lane;
-    xp[0] = pos.x; xp[1] = pos.y; xp[2] = pos.z;
-    xq[0] = quat.w; xq[1] = quat.x; xq[2] = quat.y; xq[3] = quat.z;
+    WSYNC();
+    if (lane < nb && dep >= (1 << r)) {
+      const double* a = wb + 7 * hop[r * nb + lane];
+      d4 qa = {a[3], a[4], a[5], a[6]};
+      pos = d3{a[0], a[1], a[2]} + qrot(qa, pos);
+      quat = qmul(qa, quat);
+    }
+  }
+  // the result always goes to xa; if the last round read from xa, wait before overwriting it
+  if (L.nhop > 0 && ((L.nhop - 1) & 1)) WSYNC();
+  if (lane < nb) {
+    quat = qnormalize(quat);
+    double* o = sm + L.xa + 7 * lane;
+    o[0] = pos.x; o[1] = pos.y; o[2] = pos.z; o[3] = quat.w; o[4] = quat.x; o[5] = quat.y; o[6] = quat.z;
     if (body_hinge[lane] >= 0) {
       const double* ax = sm + L.axis + 3 * lane;
       d3 aw = qrot(quat, d3{ax[0], ax[1], ax[2]});
@@ -87,6 +138,7 @@ __device__ __forceinline__ void fk_wave(const IkLayout& L, double* sm, const sho
     }
   }
   WSYNC();
+  PROF_END(pr, PH_FK);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -94,15 +146,15 @@ __device__ __forceinline__ void fk_wave(const IkLayout& L, double* sm, const sho
 // (motion_retarget.py:188-200).  lane k < K.  Returns E in every lane.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double errors_wave(const IkLayout& L, double* sm, const short* task_body,
-                                              const short* task_human, int K, int lane) {
+                                              const short* task_human, int K, int lane, Prof& pr) {
+  PROF_BEGIN(pr);
   double ss = 0.0;
   if (lane < K) {
     int b = task_body[lane], h = task_human[lane];
-    const double* xp = sm + L.xpos + 3 * b;
-    const double* xq = sm + L.xquat + 4 * b;
+    const double* x = sm + L.xa + 7 * b;
     const double* tg = sm + L.tgt + 7 * h;
     double e[6];
-    se3_log_rel(d3{xp[0], xp[1], xp[2]}, d4{xq[0], xq[1], xq[2], xq[3]}, d3{tg[0], tg[1], tg[2]},
+    se3_log_rel(d3{x[0], x[1], x[2]}, d4{x[3], x[4], x[5], x[6]}, d3{tg[0], tg[1], tg[2]},
                 d4{tg[3], tg[4], tg[5], tg[6]}, e);
     double* eo = sm + L.e + 6 * lane;
 #pragma unroll
@@ -110,6 +162,7 @@ __device__ __forceinline__ double errors_wave(const IkLayout& L, double* sm, con
   }
   ss = wave_sum(ss);
   WSYNC();
+  PROF_END(pr, PH_ERR);
   return sqrt(ss);
 }
 
@@ -117,11 +170,12 @@ __device__ __forceinline__ double errors_wave(const IkLayout& L, double* sm, con
 // QP assembly (mink compute_qp_objective + ConfigurationLimit; App. A.4-A.6)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void build_qp_wave(const IkLayout& L, double* sm, int stage, const short* task_body,
-                                              const short* task_col0, const short* task_ncol,
                                               const short* pair_task, const short* pair_dof,
                                               const short* pair_index, const short* hinge_body,
-                                              const short* limited, double damping, double lm_damping,
-                                              double limit_gain, int lane) {
+                                              const short* limited, const uint32_t* items, const int* istart,
+                                              double damping, double lm_damping, double limit_gain, int lane,
+                                              Prof& pr) {
+  PROF_BEGIN(pr);
   const int K = L.K[stage], P = L.P[stage], nv = L.nv, ldh = L.ldh;
   const double* wpos = sm + L.wpos[stage];
   const double* wrot = sm + L.wrot[stage];
@@ -147,38 +201,39 @@ __device__ __forceinline__ void build_qp_wave(const IkLayout& L, double* sm, int
     }
   }
   mu = lm_damping * wave_sum(mu);
-  // zero H (both triangles are written below)
-  double* H = sm + L.H;
-  for (int i = lane; i < nv * ldh; i += 64) H[i] = 0.0;
   WSYNC();
+  PROF_END(pr, PH_JLOG);
+  PROF_BEGIN(pr);
   // (b) lane = (task, dof) pair: weighted task-Jacobian column W_k * (-Jl^-1(e_k)) * J_body[:, d]
   double* Jw = sm + L.Jw;
-  const double* xpos = sm + L.xpos;
-  const double* xquat = sm + L.xquat;
+  double* cpart = sm + L.cpart;
+  const double* X = sm + L.xa;
   for (int p = lane; p < P; p += 64) {
     int k = pair_task[p], dof = pair_dof[p];
     int b = task_body[k];
-    d3 pb = {xpos[3 * b], xpos[3 * b + 1], xpos[3 * b + 2]};
-    d4 qb = {xquat[4 * b], xquat[4 * b + 1], xquat[4 * b + 2], xquat[4 * b + 3]};
+    d3 pb = {X[7 * b], X[7 * b + 1], X[7 * b + 2]};
+    d4 qb = {X[7 * b + 3], X[7 * b + 4], X[7 * b + 5], X[7 * b + 6]};
     d3 lin, ang;
     if (dof < 3) {
       lin = d3{dof == 0 ? 1.0 : 0.0, dof == 1 ? 1.0 : 0.0, dof == 2 ? 1.0 : 0.0};
       ang = d3{0.0, 0.0, 0.0};
     } else if (dof < 6) {
-      d4 q0 = {xquat[0], xquat[1], xquat[2], xquat[3]};
+      d4 q0 = {X[3], X[4], X[5], X[6]};
       int a = dof - 3;
       ang = qrot(q0, d3{a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0});
-      lin = cross(ang, pb - d3{xpos[0], xpos[1], xpos[2]});
+      lin = cross(ang, pb - d3{X[0], X[1], X[2]});
     } else {
       int c = hinge_body[dof - 6];
       const double* xa = sm + L.xaxis + 3 * c;
       ang = d3{xa[0], xa[1], xa[2]};
-      lin = cross(ang, pb - d3{xpos[3 * c], xpos[3 * c + 1], xpos[3 * c + 2]});
+      lin = cross(ang, pb - d3{X[7 * c], X[7 * c + 1], X[7 * c + 2]});
     }
     d3 jl = qrot_inv(qb, lin), ja = qrot_inv(qb, ang);   // body-frame Jacobian column
     const double* M = sm + L.M + 18 * k;
+    const double* we = sm + L.we + 6 * k;
     double wp = wpos[k], wr = wrot[k];
     double* o = Jw + 6 * p;
+    double cp = 0.0;
     // [ -A  -B ] [jl]      rows 0..2 (scaled by w_pos)
     // [  0  -A ] [ja]      rows 3..5 (scaled by w_rot)
 #pragma unroll
@@ -186,22 +241,24 @@ __device__ __forceinline__ void build_qp_wave(const IkLayout& L, double* sm, int
       double top = M[3 * r] * jl.x + M[3 * r + 1] * jl.y + M[3 * r + 2] * jl.z + M[9 + 3 * r] * ja.x +
                    M[9 + 3 * r + 1] * ja.y + M[9 + 3 * r + 2] * ja.z;
       double bot = M[3 * r] * ja.x + M[3 * r + 1] * ja.y + M[3 * r + 2] * ja.z;
-      o[r] = wp * top;
-      o[3 + r] = wr * bot;
+      top *= wp; bot *= wr;
+      o[r] = top;
+      o[3 + r] = bot;
+      cp += top * we[r] + bot * we[3 + r];
     }
+    cpart[p] = cp;   // this column's contribution to c = sum_k (W J_k)^T (W e_k)
   }
   WSYNC();
-  // (c) lane = dof: c = sum_k (W J_k)^T (W e_k); bounds of the limited hinges
+  PROF_END(pr, PH_PAIRS);
+  PROF_BEGIN(pr);
+  // (c) lane = dof: gather c; bounds of the limited hinges (mink ConfigurationLimit)
   if (lane < nv) {
+    int idx[GMR_MAX_TASKS];
+#pragma unroll
+    for (int k = 0; k < GMR_MAX_TASKS; k++) idx[k] = k < K ? (int)pair_index[k * nv + lane] : -1;
     double cc = 0.0;
-    for (int k = 0; k < K; k++) {
-      int p = pair_index[k * nv + lane];
-      if (p >= 0) {
-        const double* j = Jw + 6 * p;
-        const double* we = sm + L.we + 6 * k;
-        cc += j[0] * we[0] + j[1] * we[1] + j[2] * we[2] + j[3] * we[3] + j[4] * we[4] + j[5] * we[5];
-      }
-    }
+#pragma unroll
+    for (int k = 0; k < GMR_MAX_TASKS; k++) cc += idx[k] >= 0 ? cpart[idx[k]] : 0.0;
     (sm + L.c)[lane] = cc;
     double lo = -INFINITY, hi = INFINITY;
     if (lane >= 6 && limited[lane - 6]) {
@@ -212,135 +269,168 @@ __device__ __forceinline__ void build_qp_wave(const IkLayout& L, double* sm, int
     (sm + L.lo)[lane] = lo;
     (sm + L.hi)[lane] = hi;
   }
-  // (d) H += (W J_k)^T (W J_k), one task block at a time; lane = (a, b) with a >= b
-  for (int k = 0; k < K; k++) {
-    int n = task_ncol[k], c0 = task_col0[k];
-    int npair = n * (n + 1) / 2;
-    for (int idx = lane; idx < npair; idx += 64) {
-      int a = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
-      while (a * (a + 1) / 2 > idx) a--;
-      while ((a + 1) * (a + 2) / 2 <= idx) a++;
-      int b = idx - a * (a + 1) / 2;
-      const double* ja = Jw + 6 * (c0 + a);
-      const double* jb = Jw + 6 * (c0 + b);
-      double s = ja[0] * jb[0] + ja[1] * jb[1] + ja[2] * jb[2] + ja[3] * jb[3] + ja[4] * jb[4] + ja[5] * jb[5];
-      int da = pair_dof[c0 + a], db = pair_dof[c0 + b];
-      H[da * ldh + db] += s;
-      if (da != db) H[db * ldh + da] += s;
+  PROF_END(pr, PH_CVEC);
+  PROF_BEGIN(pr);
+  // (d) H: every lane sums the terms of the entries it owns (static schedule) and stores each once
+  {
+    double* H = sm + L.H;
+    const double diag = damping + mu;
+    const int i1 = istart[lane + 1];
+    int it = istart[lane];
+    double acc = 0.0;
+    uint32_t w = it < i1 ? items[it] : 0u;
+    while (it < i1) {
+      uint32_t wn = (it + 1 < i1) ? items[it + 1] : 0u;
+      if (!((w >> 30) & 1u)) acc += dot6(Jw + 6 * (w & 511u), Jw + 6 * ((w >> 9) & 511u));
+      if (w >> 31) {
+        int da = (w >> 18) & 63u, db = (w >> 24) & 63u;
+        double v = acc + (da == db ? diag : 0.0);
+        H[da * ldh + db] = v;
+        H[db * ldh + da] = v;
+        acc = 0.0;
+      }
+      w = wn;
+      it++;
     }
-    WSYNC();
   }
-  if (lane < nv) H[lane * ldh + lane] += damping + mu;
   WSYNC();
+  PROF_END(pr, PH_HACC);
 }
 
 // ---------------------------------------------------------------------------------------------
-// box-constrained strictly convex QP: primal active set, dense Cholesky in LDS (lane = row).
-// Same unique minimiser as DAQP behind qpsolvers (App. A.6).  Returns 0 ok / <0 failure; the
-// solution is left in sm[L.x].
+// box-constrained strictly convex QP  min 1/2 x^T H x + c^T x, lo <= x <= hi  (App. A.6): same
+// unique minimiser as DAQP behind qpsolvers.  Block principal pivoting over the bound sets; each
+// round is one dense Cholesky of H with the rows/columns of the fixed variables replaced by the
+// identity.  `st` (0 free, -1 at lower, +1 at upper) is carried from solve to solve (warm start).
+// Returns 0 ok / <0 failure; the solution is left in sm[L.x].
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int solve_qp_wave(const IkLayout& L, double* sm, int lane) {
+template <int NVP>
+__device__ __forceinline__ int solve_qp_regs(const IkLayout& L, double* sm, int lane, int& st, Prof& pr) {
+  constexpr int LDK = NVP + 1;
   const int n = L.nv, ldh = L.ldh;
   const double* H = sm + L.H;
-  double* Kf = sm + L.Kf;
-  const double* cvec = sm + L.c;
-  double* xs = sm + L.x;
+  double* Kt = sm + L.Kt;
   const bool act = lane < n;
+  const bool row = lane < NVP;
   const double lo = act ? (sm + L.lo)[lane] : 0.0, hi = act ? (sm + L.hi)[lane] : 0.0;
-  const double ci = act ? cvec[lane] : 0.0;
-  double x = act ? fmin(fmax(0.0, lo), hi) : 0.0;
-  int st = 0;  // 0 free, -1 at lower, +1 at upper
+  const double ci = act ? (sm + L.c)[lane] : 0.0;
+  const double* Hrow = H + (act ? lane : 0) * ldh;
+  if (!act || (st < 0 && !(lo > -INFINITY)) || (st > 0 && !(hi < INFINITY))) st = 0;
   const double dual_tol = 1e-13 * (1.0 + wave_max(fabs(ci)));
-  if (act) xs[lane] = x;
-  WSYNC();
-  for (int it = 0; it < 8 * n + 8; it++) {
-    const unsigned long long fixed = __ballot(act && st != 0);
-    // working copy K (lower triangle incl. diagonal) and right-hand side
-    double rhs = 0.0;
-    if (act) {
-      if (st != 0) rhs = x;
-      else {
-        rhs = -ci;
-        if (fixed) {
-          for (int j = 0; j < n; j++)
-            if ((fixed >> j) & 1ull) rhs -= H[lane * ldh + j] * xs[j];
-        }
-      }
-      for (int j = 0; j <= lane; j++) {
-        bool fx = (st != 0) || ((fixed >> j) & 1ull);
-        Kf[lane * ldh + j] = fx ? (j == lane ? 1.0 : 0.0) : H[lane * ldh + j];
+  const double ptol_lo = 1e-12 * (1.0 + fabs(lo)), ptol_hi = 1e-12 * (1.0 + fabs(hi));
+  int pcount = 3, ninf_best = NVP + 1;
+  for (int it = 0; it < 100; it++) {
+    PROF_BEGIN(pr);
+    PROF_COUNT(pr, PH_NFACT);
+    const unsigned long long fixedm = __ballot(act && st != 0);
+    const double xfix = st < 0 ? lo : (st > 0 ? hi : 0.0);
+    // right-hand side: fixed rows keep their bound, free rows get -c_F - H_FA x_A
+    double rhs = act ? (st != 0 ? xfix : -ci) : 0.0;
+    {
+      unsigned long long m = fixedm;
+      while (m) {
+        int j = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        double xj = readlane_d(xfix, j);
+        if (act && st == 0) rhs -= Hrow[j] * xj;
       }
     }
-    WSYNC();
-    // Cholesky, left-looking: lane i >= j forms s = K[i][j] - sum_{p<j} L[i][p] L[j][p]
-    int fail = 0;
-    for (int j = 0; j < n; j++) {
-      double s = 0.0;
-      if (act && lane >= j) {
-        s = Kf[lane * ldh + j];
-        const double* ri = Kf + lane * ldh;
-        const double* rj = Kf + j * ldh;
-        double s2 = 0.0;
-        int p = 0;
-        for (; p + 1 < j; p += 2) { s -= ri[p] * rj[p]; s2 -= ri[p + 1] * rj[p + 1]; }
-        if (p < j) s -= ri[p] * rj[p];
-        s += s2;
-      }
-      double djj = __shfl(s, j, 64);
-      if (!(djj > 0.0)) { fail = 1; break; }
-      double dinv = 1.0 / sqrt(djj);
-      if (act && lane >= j) Kf[lane * ldh + j] = (lane == j) ? djj * dinv : s * dinv;
-      WSYNC();
+    // lane i's row of the working matrix: H_ij for free i, free j <= i; identity for fixed / padding
+    const bool self_fixed = (st != 0) || !act;
+    double r[NVP];
+#pragma unroll
+    for (int k = 0; k < NVP; k++) {
+      const bool kfixed = (k >= n) || ((fixedm >> k) & 1ull);  // wave-uniform
+      double h = (act && k < n && k <= lane) ? Hrow[k] : 0.0;
+      double v = (self_fixed || kfixed) ? 0.0 : h;
+      if (k == lane && self_fixed) v = 1.0;
+      r[k] = v;
     }
-    if (fail) return GMR_STATUS_QP_FAILED;
-    // forward substitution L y = rhs (column sweep), then L^T x = y
+    PROF_END(pr, PH_KBUILD);
+    PROF_BEGIN(pr);
+    // right-looking Cholesky, row per lane, pivot column broadcast by readlane
+    double mydinv = 1.0;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NVP; j++) {
+      double dj = readlane_d(r[j], j);
+      bad = bad || !(dj > 0.0);
+      double dinv = rsqrt(dj);
+      double l = r[j] * dinv;
+      r[j] = l;
+      if (lane == j) mydinv = dinv;
+#pragma unroll
+      for (int k = j + 1; k < NVP; k++) {
+        double lk = readlane_d(l, k);
+        r[k] = fma(-l, lk, r[k]);
+      }
+    }
+    if (bad) return GMR_STATUS_QP_FAILED;
+    PROF_END(pr, PH_CHOL);
+    PROF_BEGIN(pr);
+    // forward substitution L y = rhs (column sweep)
     double b = rhs;
-    for (int j = 0; j < n; j++) {
-      double yj = __shfl(b, j, 64) / Kf[j * ldh + j];
-      if (lane == j) b = yj;
-      else if (act && lane > j) b -= Kf[lane * ldh + j] * yj;
+#pragma unroll
+    for (int j = 0; j < NVP; j++) {
+      double yj = readlane_d(b * mydinv, j);
+      double upd = fma(-r[j], yj, b);
+      b = lane == j ? yj : (lane > j ? upd : b);
     }
-    for (int j = n - 1; j >= 0; j--) {
-      double xj = __shfl(b, j, 64) / Kf[j * ldh + j];
-      if (lane == j) b = xj;
-      else if (lane < j) b -= Kf[j * ldh + lane] * xj;
+    // L^T through LDS: lane i needs column i of L
+    if (row) {
+#pragma unroll
+      for (int k = 0; k < NVP; k++) Kt[lane * LDK + k] = r[k];
     }
-    const double xe = b;
-    // ratio test against the bounds of the free variables
-    double alpha = 2.0;
-    int side = 0;
-    if (act && st == 0) {
-      double p = xe - x;
-      if (p < 0.0 && xe < lo) { alpha = (lo - x) / p; side = -1; }
-      else if (p > 0.0 && xe > hi) { alpha = (hi - x) / p; side = 1; }
-    }
-    double amin = wave_min(alpha);
-    if (amin < 1.0) {
-      unsigned long long m = __ballot(alpha == amin);
-      int blk = __ffsll((long long)m) - 1;
-      double a = fmax(amin, 0.0);
-      if (act && st == 0) x += a * (xe - x);
-      if (lane == blk) { x = side < 0 ? lo : hi; st = side; }
-      if (act) xs[lane] = x;
-      WSYNC();
-      continue;
-    }
-    x = xe;
-    if (act) xs[lane] = x;
     WSYNC();
-    if (!fixed) return GMR_STATUS_OK;
-    // multipliers of the working set: g = H x + c
-    double viol = 0.0;
-    if (act && st != 0) {
-      double g = ci;
-      for (int j = 0; j < n; j++) g += H[lane * ldh + j] * xs[j];
-      viol = st < 0 ? -g : g;
+    double lt[NVP];
+#pragma unroll
+    for (int j = 0; j < NVP; j++) lt[j] = row ? Kt[j * LDK + lane] : 0.0;
+#pragma unroll
+    for (int j = NVP - 1; j >= 0; j--) {
+      double xj = readlane_d(b * mydinv, j);
+      double upd = fma(-lt[j], xj, b);
+      b = lane == j ? xj : (lane < j ? upd : b);
     }
-    double vmax = wave_max(viol);
-    if (!(vmax > dual_tol)) return GMR_STATUS_OK;
-    unsigned long long m = __ballot(viol == vmax);
-    int rel = __ffsll((long long)m) - 1;
-    if (lane == rel) st = 0;
+    double x = b;
+    WSYNC();  // Kt is rewritten by the next round
+    PROF_END(pr, PH_SUBST);
+    PROF_BEGIN(pr);
+    // violated bounds (free set) and multipliers (fixed set): g = H x + c
+    double g = 0.0;
+    if (fixedm) {
+      g = ci;
+#pragma unroll
+      for (int j = 0; j < NVP; j++) {
+        double xj = readlane_d(x, j);
+        if (j < n) g += (act ? Hrow[j] : 0.0) * xj;
+      }
+    }
+    int newst = st;
+    bool viol = false;
+    if (act) {
+      if (st == 0) {
+        if (x < lo - ptol_lo) { viol = true; newst = -1; }
+        else if (x > hi + ptol_hi) { viol = true; newst = 1; }
+      } else if (st < 0) {
+        if (g < -dual_tol) { viol = true; newst = 0; }
+      } else {
+        if (g > dual_tol) { viol = true; newst = 0; }
+      }
+    }
+    const unsigned long long vm = __ballot(viol);
+    PROF_END(pr, PH_MULT);
+    if (vm == 0ull) {
+      if (act) (sm + L.x)[lane] = fmin(fmax(x, lo), hi);
+      WSYNC();
+      return GMR_STATUS_OK;
+    }
+    const int ninf = __popcll(vm);
+    if (ninf < ninf_best) { ninf_best = ninf; pcount = 3; st = newst; }
+    else if (pcount > 0) { pcount--; st = newst; }
+    else {  // Murty: exchange only the highest-index violated variable
+      int top = 63 - __clzll((long long)vm);
+      if (lane == top) st = newst;
+    }
   }
   return GMR_STATUS_QP_MAXITER;
 }
@@ -348,7 +438,8 @@ __device__ __forceinline__ int solve_qp_wave(const IkLayout& L, double* sm, int 
 // ---------------------------------------------------------------------------------------------
 // mj_integratePos with v = dq/dt (App. A.7): lane 0 the free joint, lane 6+h hinge h
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void integrate_wave(const IkLayout& L, double* sm, double dt, int lane) {
+__device__ __forceinline__ void integrate_wave(const IkLayout& L, double* sm, double dt, int lane, Prof& pr) {
+  PROF_BEGIN(pr);
   double* q = sm + L.q;
   const double* dq = sm + L.x;
   if (lane == 0) {
@@ -369,13 +460,15 @@ __device__ __forceinline__ void integrate_wave(const IkLayout& L, double* sm, do
     q[7 + lane - 6] += dt * v;
   }
   WSYNC();
+  PROF_END(pr, PH_INTEG);
 }
 
 // ---------------------------------------------------------------------------------------------
 // target preprocessing (motion_retarget.py:203-270).  lane b < nhuman.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void preprocess_wave(const IkLayout& L, double* sm, const short* is_foot, int human_root,
-                                                double ground_offset, int flags, int lane) {
+                                                double ground_offset, int flags, int lane, Prof& pr) {
+  PROF_BEGIN(pr);
   const double* raw = sm + L.raw;
   double* tgt = sm + L.tgt;
   double z = INFINITY;
@@ -409,25 +502,35 @@ __device__ __forceinline__ void preprocess_wave(const IkLayout& L, double* sm, c
     o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = uq.w; o[4] = uq.x; o[5] = uq.y; o[6] = uq.z;
   }
   WSYNC();
+  PROF_END(pr, PH_PRE);
 }
 
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
+template <int NVP>
 __global__ __launch_bounds__(64) void ik_streams_kernel(const gmr_model_t* __restrict__ model,
-                                                        const gmr_taskset_t* __restrict__ ts, IkLayout L, int S,
-                                                        int T, const double* __restrict__ q0,
+                                                        const gmr_taskset_t* __restrict__ ts,
+                                                        const uint32_t* __restrict__ sched, IkLayout L, int S, int T,
+                                                        const double* __restrict__ q0,
                                                         const double* __restrict__ human,
                                                         const int32_t* __restrict__ len, int flags,
                                                         double* __restrict__ q_out, int32_t* __restrict__ nsolve,
-                                                        int32_t* __restrict__ status) {
+                                                        int32_t* __restrict__ status,
+                                                        unsigned long long* __restrict__ prof_out) {
   extern __shared__ __align__(16) double smem[];
   const int lane = threadIdx.x;
   const int s = blockIdx.x;
   if (s >= S) return;
   double* sm = smem;
-  short* si = reinterpret_cast<short*>(smem + L.n_double);
-  short* chain = si + L.i_chain;
+  Prof pr;
+#ifdef GMR_IK_PROFILE
+  for (int i = 0; i < PH_COUNT; i++) pr.acc[i] = 0;
+  const unsigned long long k_t0 = __builtin_amdgcn_s_memtime(), k_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  uint32_t* sw = reinterpret_cast<uint32_t*>(smem + L.n_double);
+  short* si = reinterpret_cast<short*>(sw + L.n_word);
+  short* hop = si + L.i_hop;
   short* depth = si + L.i_depth;
   short* body_hinge = si + L.i_body_hinge;
   short* hinge_body = si + L.i_hinge_body;
@@ -441,9 +544,10 @@ __global__ __launch_bounds__(64) void ik_streams_kernel(const gmr_model_t* __res
     for (int a = 0; a < 4; a++) (sm + L.body_quat)[4 * i + a] = model->body_quat[i][a];
     int h = model->body_hinge[i];
     for (int a = 0; a < 3; a++) (sm + L.axis)[3 * i + a] = h >= 0 ? model->hinge_axis[h][a] : 0.0;
-    depth[i] = (short)model->depth[i];
+    int dep = model->depth[i];
+    depth[i] = (short)dep;
     body_hinge[i] = (short)h;
-    for (int d = 0; d < L.maxd; d++) chain[i * L.maxd + d] = (short)model->chain[i][d];
+    for (int r = 0; r < L.nhop; r++) hop[r * nb + i] = (short)(dep >= (1 << r) ? model->chain[i][dep - (1 << r)] : 0);
   }
   for (int i = lane; i < nh; i += 64) {
     (sm + L.range_lo)[i] = model->range_lo[i];
@@ -457,19 +561,16 @@ __global__ __launch_bounds__(64) void ik_streams_kernel(const gmr_model_t* __res
     for (int a = 0; a < 4; a++) (sm + L.quat_off)[4 * i + a] = ts->quat_off[i][a];
     is_foot[i] = (short)ts->is_foot[i];
   }
+  for (int i = lane; i < L.n_word; i += 64) sw[i] = sched[i];
   for (int st = 0; st < 2; st++) {
     short* tb = si + L.i_task_body[st];
     short* th = si + L.i_task_human[st];
-    short* c0 = si + L.i_task_col0[st];
-    short* nc = si + L.i_task_ncol[st];
     short* pt = si + L.i_pair_task[st];
     short* pd = si + L.i_pair_dof[st];
     short* pi = si + L.i_pair_index[st];
     for (int k = lane; k < L.K[st]; k += 64) {
       tb[k] = (short)ts->task_body[st][k];
       th[k] = (short)ts->task_human[st][k];
-      c0[k] = (short)ts->task_col0[st][k];
-      nc[k] = (short)ts->task_ncol[st][k];
       (sm + L.wpos[st])[k] = ts->w_pos[st][k];
       (sm + L.wrot[st])[k] = ts->w_rot[st][k];
     }
@@ -486,12 +587,14 @@ __global__ __launch_bounds__(64) void ik_streams_kernel(const gmr_model_t* __res
 
   for (int i = lane; i < nq; i += 64) (sm + L.q)[i] = q0[(size_t)s * nq + i];
   WSYNC();
-  fk_wave(L, sm, chain, depth, body_hinge, lane);
+  fk_wave(L, sm, hop, depth, body_hinge, lane, pr);
 
   const int Ts = len ? min(len[s], T) : T;
   const size_t fstride = (size_t)nhum * 7;
   const double* hs = human + (size_t)s * T * fstride;
   int stat = GMR_STATUS_OK;
+  int qp_state = 0;     // this lane's bound state of the previous solve (QP warm start)
+  int h_stage = -1;     // stage whose sparsity pattern H currently holds
   // first frame's raw targets
   double r0 = 0.0, r1 = 0.0;
   if (Ts > 0) {
@@ -501,7 +604,7 @@ __global__ __launch_bounds__(64) void ik_streams_kernel(const gmr_model_t* __res
   for (int t = 0; t < Ts; t++) {
     if (lane < (int)fstride) (sm + L.raw)[lane] = r0;
     if (lane + 64 < (int)fstride) (sm + L.raw)[lane + 64] = r1;
-    // prefetch the next frame (nhuman*7 <= 128 doubles): the loads stay in flight during the solve
+    // prefetch the next frame (nhuman*7 <= 128 doubles)
     if (t + 1 < Ts) {
       const double* nx = hs + (size_t)(t + 1) * fstride;
       if (lane < (int)fstride) r0 = nx[lane];
@@ -510,23 +613,31 @@ __global__ __launch_bounds__(64) void ik_streams_kernel(const gmr_model_t* __res
     WSYNC();
     int ns0 = 0, ns1 = 0;
     if (stat == GMR_STATUS_OK) {
-      preprocess_wave(L, sm, is_foot, human_root, ground_offset, flags, lane);
+      preprocess_wave(L, sm, is_foot, human_root, ground_offset, flags, lane, pr);
       for (int stage = 0; stage < 2; stage++) {
         if (!(stage == 0 ? use0 : use1)) continue;
         const short* tb = si + L.i_task_body[stage];
         const short* th = si + L.i_task_human[stage];
         const int K = L.K[stage];
-        double curr = errors_wave(L, sm, tb, th, K, lane);
+        if (h_stage != stage) {
+          // structural zeros of H are never written by the schedule: clear when the pattern changes
+          for (int i = lane; i < nv * L.ldh; i += 64) (sm + L.H)[i] = 0.0;
+          h_stage = stage;
+          WSYNC();
+        }
+        double curr = errors_wave(L, sm, tb, th, K, lane, pr);
         int nsol = 0, num_iter = 0;
         for (;;) {
-          build_qp_wave(L, sm, stage, tb, si + L.i_task_col0[stage], si + L.i_task_ncol[stage],
-                        si + L.i_pair_task[stage], si + L.i_pair_dof[stage], si + L.i_pair_index[stage],
-                        hinge_body, limited, damping, lm_damping, limit_gain, lane);
-          int rc = solve_qp_wave(L, sm, lane);
+          build_qp_wave(L, sm, stage, tb, si + L.i_pair_task[stage], si + L.i_pair_dof[stage],
+                        si + L.i_pair_index[stage], hinge_body, limited, sw + L.w_items[stage],
+                        reinterpret_cast<const int*>(sw + L.w_istart[stage]), damping, lm_damping, limit_gain,
+                        lane, pr);
+          PROF_COUNT(pr, PH_NSOLVE);
+          int rc = solve_qp_regs<NVP>(L, sm, lane, qp_state, pr);
           if (rc != GMR_STATUS_OK) { stat = rc; break; }
-          integrate_wave(L, sm, dt, lane);
-          fk_wave(L, sm, chain, depth, body_hinge, lane);
-          double next = errors_wave(L, sm, tb, th, K, lane);
+          integrate_wave(L, sm, dt, lane, pr);
+          fk_wave(L, sm, hop, depth, body_hinge, lane, pr);
+          double next = errors_wave(L, sm, tb, th, K, lane, pr);
           nsol++;
           if (nsol > 1) num_iter++;
           if (!(curr - next > tol && num_iter < max_iter)) break;
@@ -542,23 +653,50 @@ __global__ __launch_bounds__(64) void ik_streams_kernel(const gmr_model_t* __res
     WSYNC();
   }
   if (lane == 0) status[s] = stat;
+#ifdef GMR_IK_PROFILE
+  pr.acc[PH_TICKS] = __builtin_amdgcn_s_memtime() - k_t0;
+  pr.acc[PH_REALTIME] = __builtin_amdgcn_s_memrealtime() - k_r0;
+  if (lane == 0 && prof_out)
+    for (int i = 0; i < PH_COUNT; i++) prof_out[(size_t)s * PH_COUNT + i] = pr.acc[i];
+#else
+  (void)prof_out;
+#endif
 }
 
 }  // namespace gmr
 
 // host-side launcher used by gmr_abi.hip
-extern "C" hipError_t gmr_launch_ik_streams(const gmr_model_t* d_model, const gmr_taskset_t* d_ts,
-                                            const gmr::IkLayout* L, int S, int T, const double* d_q0,
-                                            const double* d_human, const int32_t* d_len, int flags,
-                                            double* d_q_out, int32_t* d_nsolve, int32_t* d_status,
-                                            hipStream_t stream) {
-  if (S <= 0 || T <= 0) return hipSuccess;
-  hipLaunchKernelGGL(gmr::ik_streams_kernel, dim3(S), dim3(64), L->smem_bytes, stream, d_model, d_ts, *L, S, T,
-                     d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status);
+template <int NVP>
+static hipError_t launch_nvp(const gmr_model_t* d_model, const gmr_taskset_t* d_ts, const uint32_t* d_sched,
+                             const gmr::IkLayout* L, int S, int T, const double* d_q0, const double* d_human,
+                             const int32_t* d_len, int flags, double* d_q_out, int32_t* d_nsolve, int32_t* d_status,
+                             hipStream_t stream, unsigned long long* d_prof) {
+  hipLaunchKernelGGL(gmr::ik_streams_kernel<NVP>, dim3(S), dim3(64), L->smem_bytes, stream, d_model, d_ts, d_sched,
+                     *L, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, d_prof);
   return hipGetLastError();
 }
 
-extern "C" hipError_t gmr_ik_set_max_smem(int bytes) {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(gmr::ik_streams_kernel),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+extern "C" hipError_t gmr_launch_ik_streams(const gmr_model_t* d_model, const gmr_taskset_t* d_ts,
+                                            const uint32_t* d_sched, const gmr::IkLayout* L, int S, int T,
+                                            const double* d_q0, const double* d_human, const int32_t* d_len,
+                                            int flags, double* d_q_out, int32_t* d_nsolve, int32_t* d_status,
+                                            hipStream_t stream, unsigned long long* d_prof) {
+  if (S <= 0 || T <= 0) return hipSuccess;
+  switch (L->nvp) {
+    case 28: return launch_nvp<28>(d_model, d_ts, d_sched, L, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream, d_prof);
+    case 32: return launch_nvp<32>(d_model, d_ts, d_sched, L, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream, d_prof);
+    case 36: return launch_nvp<36>(d_model, d_ts, d_sched, L, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream, d_prof);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+extern "C" hipError_t gmr_ik_set_max_smem(int nvp, int bytes) {
+  const void* f = nullptr;
+  switch (nvp) {
+    case 28: f = reinterpret_cast<const void*>(gmr::ik_streams_kernel<28>); break;
+    case 32: f = reinterpret_cast<const void*>(gmr::ik_streams_kernel<32>); break;
+    case 36: f = reinterpret_cast<const void*>(gmr::ik_streams_kernel<36>); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }

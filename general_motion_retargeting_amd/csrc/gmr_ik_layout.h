@@ -1,62 +1,147 @@
-// gmr_ik_layout.h -- LDS carve-up of one IK stream (shared by host launcher and kernel).
+// gmr_ik_layout.h -- LDS carve-up of one IK stream and the static H-assembly schedule
+// (shared by the host launcher and the kernel).
 #pragma once
 #include <stdint.h>
+
+#include <algorithm>
+#include <vector>
 
 #include "../../include/gmr_types.h"
 
 namespace gmr {
 
+constexpr int IK_MAX_HOPS = 5;  // pointer-jumping rounds of the FK: 2^5 = 32 > GMR_MAX_DEPTH
+
 struct IkLayout {
   // dimensions
-  int nb, nh, nq, nv, nhum, maxd, ldh;
-  int K[2], P[2];
+  int nb, nh, nq, nv, nvp, nhum, maxd, nhop, ldh;
+  int K[2], P[2], nitem[2];
   // offsets in doubles
   int body_pos, body_quat, axis, range_lo, range_hi, scale, pos_off, quat_off;
   int wpos[2], wrot[2];
-  int q, lq, xpos, xquat, xaxis, raw, tgt, e, we, M, Jw, H, Kf, c, x, lo, hi;
+  int q, xa, xb, xaxis, raw, tgt, e, we, M, Jw, cpart, H, Kt, c, x, lo, hi;
   int n_double;
-  // offsets in shorts (after the doubles)
-  int i_chain, i_depth, i_body_hinge, i_hinge_body, i_limited, i_is_foot;
-  int i_task_body[2], i_task_human[2], i_task_col0[2], i_task_ncol[2], i_pair_task[2], i_pair_dof[2],
-      i_pair_index[2];
+  // offsets in 32-bit words (after the doubles): the H-assembly schedule
+  int w_items[2], w_istart[2];
+  int n_word;
+  // offsets in shorts (after the words)
+  int i_hop, i_depth, i_body_hinge, i_hinge_body, i_limited, i_is_foot;
+  int i_task_body[2], i_task_human[2], i_pair_task[2], i_pair_dof[2], i_pair_index[2];
   int n_short;
   int smem_bytes;
 };
 
-inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts) {
+// rows of the dense register-resident factorisation are padded to one of these sizes
+inline int ik_padded_nv(int nv) {
+  if (nv <= 28) return 28;
+  if (nv <= 32) return 32;
+  if (nv <= 36) return 36;
+  return -1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Static schedule of H = sum_k (W J_k)^T (W J_k): the Jacobian of task k is non-zero only on the
+// dofs of its root->frame path, so H[i][j] only receives terms from tasks whose path holds both i
+// and j.  Every (i >= j) entry with its list of (pair_a, pair_b) terms is owned by exactly ONE lane
+// (longest-processing-time assignment), which sums the terms in a fixed order in a register and
+// stores the entry once: no read-modify-write, no atomics, deterministic.
+// item word: [8:0] pair a, [17:9] pair b, [23:18] dof i, [29:24] dof j, [30] entry has no term,
+//            [31] last term of the entry
+// ---------------------------------------------------------------------------------------------
+struct IkSchedule {
+  std::vector<uint32_t> items[2];
+  int istart[2][65];
+};
+
+inline IkSchedule make_ik_schedule(const gmr_model_t& m, const gmr_taskset_t& ts) {
+  IkSchedule sch;
+  const int nv = m.nv;
+  for (int s = 0; s < 2; s++) {
+    std::vector<std::vector<uint32_t>> terms((size_t)nv * nv);
+    for (int k = 0; k < ts.ntask[s]; k++) {
+      int c0 = ts.task_col0[s][k], n = ts.task_ncol[s][k];
+      for (int a = 0; a < n; a++)
+        for (int b = 0; b <= a; b++) {
+          int da = ts.pair_dof[s][c0 + a], db = ts.pair_dof[s][c0 + b];
+          terms[(size_t)da * nv + db].push_back((uint32_t)(c0 + a) | ((uint32_t)(c0 + b) << 9));
+        }
+    }
+    struct Ent { int da, db, w; };
+    std::vector<Ent> ents;
+    for (int da = 0; da < nv; da++)
+      for (int db = 0; db <= da; db++) {
+        int w = (int)terms[(size_t)da * nv + db].size();
+        if (w > 0 || da == db) ents.push_back({da, db, w});
+      }
+    std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.w > y.w; });
+    std::vector<std::vector<Ent>> per_lane(64);
+    int load[64] = {0};
+    for (const Ent& e : ents) {
+      int best = 0;
+      for (int l = 1; l < 64; l++) if (load[l] < load[best]) best = l;
+      per_lane[best].push_back(e);
+      load[best] += std::max(e.w, 1) + 1;  // +1: the two stores of the entry
+    }
+    sch.items[s].clear();
+    for (int l = 0; l < 64; l++) {
+      sch.istart[s][l] = (int)sch.items[s].size();
+      for (const Ent& e : per_lane[l]) {
+        const auto& t = terms[(size_t)e.da * nv + e.db];
+        uint32_t dd = ((uint32_t)e.da << 18) | ((uint32_t)e.db << 24);
+        if (t.empty()) sch.items[s].push_back(dd | (1u << 30) | (1u << 31));
+        for (size_t i = 0; i < t.size(); i++)
+          sch.items[s].push_back(t[i] | dd | (i + 1 == t.size() ? (1u << 31) : 0u));
+      }
+    }
+    sch.istart[s][64] = (int)sch.items[s].size();
+  }
+  return sch;
+}
+
+inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, const IkSchedule& sch) {
   IkLayout L{};
   L.nb = m.nbody; L.nh = m.nhinge; L.nq = m.nq; L.nv = m.nv; L.nhum = ts.nhuman;
+  L.nvp = ik_padded_nv(m.nv);
   int maxd = 1;
   for (int b = 0; b < m.nbody; b++) if (m.depth[b] + 1 > maxd) maxd = m.depth[b] + 1;
   L.maxd = maxd;
+  L.nhop = 0;
+  while ((1 << L.nhop) < maxd) L.nhop++;
   L.ldh = (m.nv % 2 == 0) ? m.nv + 1 : m.nv + 2;  // odd row stride (in doubles): conflict-free column reads
-  for (int s = 0; s < 2; s++) { L.K[s] = ts.ntask[s]; L.P[s] = ts.npair[s]; }
-  int Kmax = L.K[0] > L.K[1] ? L.K[0] : L.K[1];
-  int Pmax = L.P[0] > L.P[1] ? L.P[0] : L.P[1];
+  for (int s = 0; s < 2; s++) { L.K[s] = ts.ntask[s]; L.P[s] = ts.npair[s]; L.nitem[s] = (int)sch.items[s].size(); }
+  int Kmax = std::max(L.K[0], L.K[1]);
+  int Pmax = std::max(L.P[0], L.P[1]);
   int o = 0;
   auto D = [&](int n) { int r = o; o += n; return r; };
   L.body_pos = D(3 * L.nb); L.body_quat = D(4 * L.nb); L.axis = D(3 * L.nb);
   L.range_lo = D(L.nh); L.range_hi = D(L.nh);
   L.scale = D(L.nhum); L.pos_off = D(3 * L.nhum); L.quat_off = D(4 * L.nhum);
   for (int s = 0; s < 2; s++) { L.wpos[s] = D(L.K[s]); L.wrot[s] = D(L.K[s]); }
-  L.q = D(L.nq + 1); L.lq = D(4 * L.nb); L.xpos = D(3 * L.nb); L.xquat = D(4 * L.nb); L.xaxis = D(3 * L.nb);
+  L.q = D(L.nq + 1);
+  L.xa = D(7 * L.nb + 1); L.xb = D(7 * L.nb + 1);   // ping-pong (pos, quat) of the FK rounds
+  L.xaxis = D(3 * L.nb);
   L.raw = D(7 * L.nhum + 1); L.tgt = D(7 * L.nhum + 1);
-  L.e = D(6 * Kmax); L.we = D(6 * Kmax); L.M = D(18 * Kmax); L.Jw = D(6 * Pmax);
-  L.H = D(L.nv * L.ldh); L.Kf = D(L.nv * L.ldh);
+  L.e = D(6 * Kmax); L.we = D(6 * Kmax); L.M = D(18 * Kmax); L.Jw = D(6 * Pmax); L.cpart = D(Pmax);
+  L.H = D(L.nv * L.ldh + 2);
+  L.Kt = D(L.nvp * (L.nvp + 1));
   L.c = D(L.nv); L.x = D(L.nv); L.lo = D(L.nv); L.hi = D(L.nv);
   L.n_double = o;
+  int w = 0;
+  auto W = [&](int n) { int r = w; w += n; return r; };
+  for (int s = 0; s < 2; s++) { L.w_items[s] = W(L.nitem[s]); L.w_istart[s] = W(65); }
+  if (w % 2) w++;
+  L.n_word = w;
   int i = 0;
   auto I = [&](int n) { int r = i; i += n; return r; };
-  L.i_chain = I(L.nb * maxd); L.i_depth = I(L.nb); L.i_body_hinge = I(L.nb);
+  L.i_hop = I(IK_MAX_HOPS * L.nb); L.i_depth = I(L.nb); L.i_body_hinge = I(L.nb);
   L.i_hinge_body = I(L.nh); L.i_limited = I(L.nh); L.i_is_foot = I(L.nhum);
   for (int s = 0; s < 2; s++) {
     L.i_task_body[s] = I(L.K[s]); L.i_task_human[s] = I(L.K[s]);
-    L.i_task_col0[s] = I(L.K[s]); L.i_task_ncol[s] = I(L.K[s]);
     L.i_pair_task[s] = I(L.P[s]); L.i_pair_dof[s] = I(L.P[s]);
-    L.i_pair_index[s] = I(L.K[s] * L.nv);
+    L.i_pair_index[s] = I(GMR_MAX_TASKS * L.nv);
   }
   L.n_short = i;
-  L.smem_bytes = L.n_double * 8 + ((L.n_short * 2 + 15) / 16) * 16;
+  L.smem_bytes = L.n_double * 8 + L.n_word * 4 + ((L.n_short * 2 + 15) / 16) * 16;
   return L;
 }
 
