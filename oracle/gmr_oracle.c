@@ -636,3 +636,44 @@ int orc_has_openmp(void) {
   return 0;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* flat entry points for the property tests (finite differences, KKT checks)                   */
+/* ------------------------------------------------------------------------------------------ */
+/* e_out[K][6]; returns the unweighted norm */
+double orc_stage_error_flat(const gmr_model_t* m, const gmr_taskset_t* ts, int stage, const double* q_in,
+                            const double* tgt, double* e_out) {
+  orc_fk_t k;
+  double q[GMR_MAX_NQ + 1], e[NK][6];
+  memcpy(q, q_in, m->nq * sizeof(double));
+  orc_fk(m, q, &k);
+  double E = orc_stage_error(m, ts, stage, &k, tgt, e);
+  memcpy(e_out, e, sizeof(double) * 6 * ts->ntask[stage]);
+  return E;
+}
+
+/* J_out[K][6][nv] (dense, row-major with row length nv) */
+void orc_task_jacobians_flat(const gmr_model_t* m, const gmr_taskset_t* ts, int stage, const double* q_in,
+                             const double* tgt, double* J_out) {
+  orc_fk_t k;
+  double q[GMR_MAX_NQ + 1], e[NK][6], J[6][NV];
+  memcpy(q, q_in, m->nq * sizeof(double));
+  orc_fk(m, q, &k);
+  orc_stage_error(m, ts, stage, &k, tgt, e);
+  for (int t = 0; t < ts->ntask[stage]; t++) {
+    orc_task_jacobian(m, &k, ts->task_body[stage][t], e[t], J);
+    for (int r = 0; r < 6; r++)
+      for (int d = 0; d < m->nv; d++) J_out[((size_t)t * 6 + r) * m->nv + d] = J[r][d];
+  }
+}
+
+/* H[nv][nv], c, lo, hi of the QP solve_ik would build at q */
+void orc_build_qp_flat(const gmr_model_t* m, const gmr_taskset_t* ts, int stage, const double* q_in,
+                       const double* tgt, double* H, double* c, double* lo, double* hi) {
+  orc_fk_t k;
+  double q[GMR_MAX_NQ + 1], e[NK][6];
+  memcpy(q, q_in, m->nq * sizeof(double));
+  orc_fk(m, q, &k);
+  orc_stage_error(m, ts, stage, &k, tgt, e);
+  orc_build_qp(m, ts, stage, q, &k, e, H, c, lo, hi);
+}

@@ -140,3 +140,34 @@ def fk_f32(tree, root_pos, root_rot, dof):
                      _p(_c(tree["local_rotation"], np.float32)), _p(_c(tree["dof_idx"], np.int32)),
                      _p(_c(tree["axis"], np.float64)), nd, B, _p(root_pos), _p(root_rot), _p(dof), _p(bp), _p(br))
     return bp, br
+
+
+def stage_error(model, ts, stage, q, tgt):
+    K = int(ts["ntask"][0][stage])
+    e = np.empty((K, 6))
+    L = lib()
+    L.orc_stage_error_flat.restype = C.c_double
+    E = L.orc_stage_error_flat(_p(model), _p(ts), int(stage), _p(_c(q, np.float64)), _p(_c(tgt, np.float64)), _p(e))
+    return e, float(E)
+
+
+def task_jacobians(model, ts, stage, q, tgt):
+    K = int(ts["ntask"][0][stage])
+    nv = int(model["nv"][0])
+    J = np.empty((K, 6, nv))
+    lib().orc_task_jacobians_flat(_p(model), _p(ts), int(stage), _p(_c(q, np.float64)), _p(_c(tgt, np.float64)), _p(J))
+    return J
+
+
+def build_qp(model, ts, stage, q, tgt):
+    nv = int(model["nv"][0])
+    H = np.empty((nv, nv)); c = np.empty(nv); lo = np.empty(nv); hi = np.empty(nv)
+    lib().orc_build_qp_flat(_p(model), _p(ts), int(stage), _p(_c(q, np.float64)), _p(_c(tgt, np.float64)),
+                            _p(H), _p(c), _p(lo), _p(hi))
+    return H, c, lo, hi
+
+
+def integrate(model, q, dq):
+    q = _c(q, np.float64).copy()
+    lib().orc_integrate(_p(model), _p(q), _p(_c(dq, np.float64)))
+    return q

@@ -160,3 +160,109 @@ def test_fk_batch_large_and_edge_sizes(hip, oracle):
         assert mz == bp[..., 2].min()
         bp2, br2, _ = fk.fk(rp, rq, dof, want_rot=False)
         assert br2 is None and np.array_equal(bp2, bp)
+
+
+# ----------------------------------------------------------------------------------------------
+# the reference-shaped host API on the GPU
+# ----------------------------------------------------------------------------------------------
+def test_shim_per_frame_equals_clip_equals_oracle(hip, oracle, g1):
+    from general_motion_retargeting_amd import GeneralMotionRetargeting, synth
+    human, q0 = synth.make_streams(g1.model, g1.tt, 2, 10, seed=13)
+    q_o, ns_o, _ = oracle.retarget_streams(g1.mb, g1.ts, q0, human)
+    g = GeneralMotionRetargeting("smplx", "unitree_g1")
+    frames = synth.streams_to_dicts(g1.tt, human[0])
+    per_frame = np.array([g.retarget(f) for f in frames])            # scripts/smplx_to_robot.py loop
+    assert per_frame.dtype == np.float64 and per_frame.shape == (10, 36)
+    assert np.abs(per_frame - q_o[0]).max() <= TOL_RAD
+    assert np.array_equal(g.last_num_solves, ns_o[0, -1])
+    assert set(g.scaled_human_data) == set(g1.tt.human_names)
+    g2 = GeneralMotionRetargeting("smplx", "unitree_g1")
+    clip = g2.retarget_clip(frames[:6])
+    clip2 = g2.retarget_clip(frames[6:])                              # continues from the stored configuration
+    # the QP active set is warm-started inside a launch but not across launches: same minimiser,
+    # different pivoting path => agreement to rounding, not to the bit
+    assert np.abs(np.concatenate([clip, clip2]) - per_frame).max() <= 1e-12
+    out = g2.retarget(frames[0])
+    out[:] = 0                                                        # a fresh copy, not a view of the state
+    assert np.abs(g2.configuration.q).max() > 0
+    with pytest.raises(RuntimeError):
+        bad = synth.streams_to_dicts(g1.tt, human[1])[0]
+        bad["pelvis"] = (np.array([np.nan, 0, 0]), bad["pelvis"][1])
+        GeneralMotionRetargeting("smplx", "unitree_g1").retarget(bad)
+
+
+def test_shim_offset_to_ground(hip, oracle, g1):
+    from general_motion_retargeting_amd import GeneralMotionRetargeting, synth
+    human, q0 = synth.make_streams(g1.model, g1.tt, 1, 4, seed=2)
+    q_o, _, _ = oracle.retarget_streams(g1.mb, g1.ts, q0, human, offset_to_ground=True)
+    g = GeneralMotionRetargeting("smplx", "unitree_g1")
+    for t, f in enumerate(synth.streams_to_dicts(g1.tt, human[0])):
+        assert np.abs(g.retarget(f, offset_to_ground=True) - q_o[0, t]).max() <= TOL_RAD
+    feet = [g.scaled_human_data[n][0][2] for n in g.scaled_human_data if "foot" in n]
+    assert abs(min(feet) - 0.1) < 1e-12
+
+
+def test_kinematics_model_numpy_and_torch_paths(hip, oracle):
+    import os
+    from conftest import GOLDEN
+    from general_motion_retargeting_amd import KinematicsModel, ROBOT_XML_DICT
+    g = np.load(os.path.join(GOLDEN, "g_fk.npz"))
+    km = KinematicsModel(ROBOT_XML_DICT["unitree_g1"], device="cuda:0")
+    assert km.num_dof == 29 and km.num_joint == 38 and km.body_names[0] == "pelvis"
+    rp, rr, dof = g["unitree_g1__root_pos"], g["unitree_g1__root_rot"], g["unitree_g1__dof"]
+    bp, br = km.forward_kinematics(rp, rr, dof)
+    assert np.abs(bp - g["unitree_g1__body_pos"]).max() <= 2e-6
+    bp3, br3 = km.forward_kinematics(rp.reshape(4, 6, 3), rr.reshape(4, 6, 4), dof.reshape(4, 6, 29))   # leading dims
+    assert bp3.shape == (4, 6, 38, 3) and np.array_equal(bp3.reshape(bp.shape), bp)
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        t = lambda a: torch.from_numpy(a).to("cuda:0")
+        tbp, tbr = km.forward_kinematics(t(rp), t(rr), t(dof))        # zero-copy on torch device memory
+        assert tbp.is_cuda and tbp.dtype == torch.float32
+        assert np.array_equal(tbp.cpu().numpy(), bp) and np.array_equal(tbr.cpu().numpy(), br)
+        lowest = torch.min(tbp[..., 2]).item()                        # what the dataset script does (:125)
+        _, _, mz = km.forward_kinematics(t(rp), t(rr), t(dof), return_min_z=True)
+        assert mz == lowest
+    cbp, _ = km.forward_kinematics(torch.from_numpy(rp), torch.from_numpy(rr), torch.from_numpy(dof))
+    assert np.array_equal(cbp.numpy(), bp)
+
+
+def test_dataset_harness_many_clips_one_launch(hip, oracle, g1):
+    from general_motion_retargeting_amd import dataset, synth
+    lens = [7, 12, 1, 9]
+    human, q0 = synth.make_streams(g1.model, g1.tt, 4, 12, seed=31)
+    clips = [human[i, :n] for i, n in enumerate(lens)]
+    out = dataset.retarget_clips("smplx", "unitree_g1", clips, fps=[30.0] * 4)
+    assert len(out) == 4
+    for i, n in enumerate(lens):
+        q_o, _, _ = oracle.retarget_streams(g1.mb, g1.ts, q0[i:i + 1], human[i:i + 1, :n])
+        md = out[i]
+        assert md["dof_pos"].shape == (n, 29) and np.abs(md["dof_pos"] - q_o[0, :, 7:]).max() <= TOL_RAD
+        assert np.abs(md["root_rot"] - q_o[0][:, [4, 5, 6, 3]]).max() <= TOL_RAD
+        assert md["local_body_pos"].shape == (n, 38, 3) and md["local_body_pos"].dtype == np.float32
+        assert np.abs(md["root_pos"][0, :2]).max() == 0
+        from general_motion_retargeting_amd import KinematicsModel, ROBOT_XML_DICT
+        km = KinematicsModel(ROBOT_XML_DICT["unitree_g1"])
+        bp, _ = km.forward_kinematics(md["root_pos"], md["root_rot"], md["dof_pos"])
+        assert abs(float(bp[..., 2].min())) < 2e-6                    # lowest body part sits on the ground
+
+
+def test_full_size_config2_properties(hip, oracle, g1):
+    """BASELINE.json configs[1] at full size (S=100 x T=100): iteration counts and joint angles
+    against the oracle on every frame, limits respected, unit root quaternions, streams independent."""
+    from general_motion_retargeting_amd import synth
+    human, q0 = synth.make_streams(g1.model, g1.tt, 100, 100, seed=0)
+    sol = hip.Solver(g1.mb, g1.ts)
+    q_h, ns_h, st_h = sol.retarget_streams(q0, human)
+    assert (st_h == 0).all()
+    assert (ns_h >= 1).all() and (ns_h <= 11).all()
+    assert np.abs(np.linalg.norm(q_h[..., 3:7], axis=-1) - 1).max() < 1e-14
+    assert (q_h[..., 7:] >= g1.model.range_lo - 1e-12).all() and (q_h[..., 7:] <= g1.model.range_hi + 1e-12).all()
+    import os
+    q_o, ns_o, st_o = oracle.retarget_streams(g1.mb, g1.ts, q0, human, nthreads=os.cpu_count() or 1)
+    assert np.array_equal(ns_h, ns_o)
+    joint, pos, rot = _compare(q_h, q_o)
+    assert joint <= 1e-8 and pos <= 1e-8 and rot <= 1e-8, (joint, pos, rot)   # contract: 1e-4 rad
+    perm = np.random.default_rng(0).permutation(100)[:17]
+    q_p, _, _ = sol.retarget_streams(q0[perm], human[perm])
+    assert np.array_equal(q_p, q_h[perm])

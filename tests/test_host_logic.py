@@ -1,0 +1,131 @@
+"""Host-side logic that needs no GPU: packing of human_data dicts, error conventions, LPT
+sharding, the dataset post-processing (with the FK supplied by the oracle), synthetic generator."""
+import numpy as np
+import pytest
+
+from conftest import get_setup
+from general_motion_retargeting_amd import GeneralMotionRetargeting, TargetNotSet, synth
+from general_motion_retargeting_amd.sharding import lpt_partition
+
+
+def test_pack_frame_and_keyerrors(g1):
+    g = GeneralMotionRetargeting("smplx", "unitree_g1")
+    human, _ = synth.make_streams(g1.model, g1.tt, 1, 2, seed=0)
+    hd = synth.streams_to_dicts(g1.tt, human[0])[0]
+    hd["extra_body"] = ([0, 0, 0], [1, 0, 0, 0])                      # extra bodies are dropped (:218-220)
+    packed = g.pack_frame(g.to_numpy(hd))
+    assert np.array_equal(packed, human[0, 0])
+    missing = dict(hd); del missing["left_wrist"]
+    with pytest.raises(KeyError, match="left_wrist"):
+        g.pack_frame(missing)
+    noroot = dict(hd); del noroot["pelvis"]
+    with pytest.raises(KeyError, match="pelvis"):
+        g.pack_frame(noroot)
+    assert g.pack_frames([]).shape == (0, 14, 7)
+
+
+def test_duplicate_human_body_is_target_not_set(g1):
+    g = GeneralMotionRetargeting("smplx", "unitree_g1")
+    g._tables.stages[0].human_names[1] = g._tables.stages[0].human_names[2]
+    human, _ = synth.make_streams(g1.model, g1.tt, 1, 1, seed=0)
+    with pytest.raises(TargetNotSet):
+        g.pack_frame(synth.streams_to_dicts(g1.tt, human[0])[0])
+
+
+def test_constructor_attributes_match_reference_surface():
+    g = GeneralMotionRetargeting("smplx", "hightorque_hi", actual_human_height=1.7, damping=0.25)
+    assert g.xml_file.endswith((".xml", ".npz")) and g.max_iter == 10 and g.damping == 0.25 and g.solver == "daqp"
+    assert np.allclose(g.ground, [0, 0, -0.05]) and g.use_ik_match_table1 and g.use_ik_match_table2
+    assert abs(g.human_scale_table["pelvis"] / (1.7 / 1.8) - g._tables.scale_table["pelvis"] / (1.7 / 1.8)) < 1e-15
+    assert g.configuration.q.shape == (g.model.nq,) and np.array_equal(g.configuration.q, g.model.qpos0)
+    # ground is subtracted from the LOCAL offset before rotation (:91): preserved quirk
+    name = g._tables.stages[0].human_names[0]
+    raw = np.array(g.ik_match_table1[g._tables.stages[0].frame_names[0]][3])
+    assert np.allclose(g.pos_offsets1[name], raw - g.ground)
+    assert g._taskset_blob["damping"][0] == 0.25
+
+
+def test_error_functions_follow_reference_definition(oracle, g1):
+    g = GeneralMotionRetargeting("smplx", "unitree_g1")
+    human, q0, truth = synth.make_streams(g1.model, g1.tt, 1, 3, seed=9, return_truth=True)
+    with pytest.raises(TargetNotSet):
+        g.error1()
+    g.update_targets(synth.streams_to_dicts(g1.tt, human[0])[1])
+    g.configuration.update(truth[0, 0])
+    tgt = oracle.preprocess(g1.ts, human[0, 1])
+    for stage, fn in ((0, g.error1), (1, g.error2)):
+        _, E = oracle.stage_error(g1.mb, g1.ts, stage, truth[0, 0], tgt)
+        assert abs(fn() - E) < 1e-12
+
+
+def test_lpt_partition_properties():
+    rng = np.random.default_rng(0)
+    lens = rng.integers(1, 9000, size=77)                              # LAFAN1-shaped: 77 ragged streams
+    parts = lpt_partition(lens, 8)
+    flat = sorted(i for p in parts for i in p)
+    assert flat == list(range(77))
+    loads = [int(lens[p].sum()) for p in parts]
+    assert max(loads) - min(loads) <= lens.max()
+    assert lpt_partition(lens, 8) == parts                             # deterministic
+    assert lpt_partition([5, 5], 4) == [[0], [1], [], []]
+    assert lpt_partition([], 2) == [[], []]
+
+
+def test_dataset_postprocess_matches_reference_recipe(oracle, g1, monkeypatch):
+    """H10 with the FK kernel replaced by the oracle's float32 FK (CPU): checks the recipe itself."""
+    from general_motion_retargeting_amd import KinematicsModel, ROBOT_XML_DICT, dataset
+
+    class FakeHandle:
+        def __init__(self, tree):
+            self.tree = tree
+
+        def fk(self, rp, rr, dof, want_rot=True, want_min_z=False):
+            bp, br = oracle.fk_f32(self.tree, rp, rr, dof)
+            return bp, br, (float(bp[..., 2].min()) if want_min_z else None)
+
+    km = KinematicsModel(ROBOT_XML_DICT["unitree_g1"])
+    km._handle = FakeHandle(km._tree)
+    human, q0 = synth.make_streams(g1.model, g1.tt, 1, 8, seed=4)
+    qpos, _, _ = oracle.retarget_streams(g1.mb, g1.ts, q0, human)
+    qpos = qpos[0]
+    md = dataset.postprocess_clip(qpos, km, fps=30.0)
+    assert list(md) == ["fps", "root_pos", "root_rot", "dof_pos", "local_body_pos", "link_body_list"]
+    assert np.array_equal(md["root_rot"], qpos[:, [4, 5, 6, 3]]) and np.array_equal(md["dof_pos"], qpos[:, 7:])
+    assert md["local_body_pos"].dtype == np.float32 and md["local_body_pos"].shape == (8, 38, 3)
+    assert md["link_body_list"] == km.body_names and md["root_pos"].dtype == np.float64
+    bp, _ = oracle.fk_f32(km._tree, qpos[:, :3].astype(np.float32), qpos[:, [4, 5, 6, 3]].astype(np.float32),
+                          qpos[:, 7:].astype(np.float32))
+    exp = qpos[:, :3].copy()
+    exp[:, 2] -= float(bp[..., 2].min())
+    exp[:, :2] -= exp[0, :2]
+    assert np.array_equal(md["root_pos"], exp)
+    assert np.array_equal(md["root_pos"][0, :2], [0, 0])
+    md2 = dataset.postprocess_clip(qpos, km, fps=30.0, height_adjust=False, root_origin_offset=False)   # BVH script
+    assert np.array_equal(md2["root_pos"], qpos[:, :3])
+    # pkl round trip through the loader (root_rot back to wxyz)
+    import os, tempfile
+    from general_motion_retargeting_amd import load_robot_motion, save_robot_motion
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "m.pkl")
+        save_robot_motion(p, md)
+        data, fps, rp, rr, dp, lbp, names = load_robot_motion(p)
+        assert fps == 30.0 and np.array_equal(rr, qpos[:, 3:7]) and names == km.body_names
+
+
+def test_synthetic_generator_is_seeded_and_invertible(oracle, g1):
+    h1, q1 = synth.make_streams(g1.model, g1.tt, 3, 5, seed=42)
+    h2, q2 = synth.make_streams(g1.model, g1.tt, 3, 5, seed=42)
+    assert np.array_equal(h1, h2) and np.array_equal(q1, q2)
+    h3, _ = synth.make_streams(g1.model, g1.tt, 2, 5, seed=43)
+    assert np.array_equal(h3[0], h1[1])                                # stream s uses seed + s
+    # without noise, preprocessing the generated raw data reproduces the task-frame poses of q*
+    h, q0, truth = synth.make_streams(g1.model, g1.tt, 1, 3, seed=1, pos_noise=0, rot_noise_deg=0, return_truth=True)
+    tgt = oracle.preprocess(g1.ts, h[0, 2])
+    xpos, xquat = synth.fk_numpy(g1.model, truth[0, 2])
+    st = g1.tt.stages[0]
+    for fr, hb in zip(st.frame_names, st.human_names):
+        i, b = g1.tt.human_names.index(hb), g1.model.body_id(fr)
+        assert np.abs(tgt[i, :3] - xpos[b]).max() < 1e-12
+        assert min(np.abs(tgt[i, 3:] - xquat[b]).max(), np.abs(tgt[i, 3:] + xquat[b]).max()) < 1e-12
+    lo, hi = g1.model.range_lo, g1.model.range_hi
+    assert (truth[..., 7:] >= lo).all() and (truth[..., 7:] <= hi).all()
