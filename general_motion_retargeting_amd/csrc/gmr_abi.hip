@@ -1,6 +1,7 @@
 // gmr_abi.hip -- the C-ABI of libgmrhip.so (include/gmr_hip.h): handles, memory/stream/event
 // helpers and the host side of the two launches.  No compute happens here.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -318,13 +319,26 @@ int gmr_fk_create(int nbody, const int32_t* parent, const float* local_t, const 
   }
   if (maxd > gmr::FK_MAX_DEPTH) { delete k; return fail(GMR_ERR_ARG, "tree too deep"); }
   t.maxd = maxd;
+  // LDS slots: bodies with >= 2 children are parked; a later child reloads its parent from the slot
+  {
+    int nchild[gmr::FK_MAX_BODIES] = {0};
+    for (int b = 1; b < nbody; b++) nchild[parent[b]]++;
+    int ns = 0;
+    for (int b = 0; b < nbody; b++) t.save_slot[b] = (short)(nchild[b] >= 2 ? ns++ : -1);
+    t.nslot = ns > 0 ? ns : 1;
+    t.load_slot[0] = -1;
+    for (int b = 1; b < nbody; b++) t.load_slot[b] = (short)(parent[b] == b - 1 ? -1 : t.save_slot[parent[b]]);
+  }
   for (int b = 0; b < nbody; b++) {
     if (dof_idx[b] >= ndof) { delete k; return fail(GMR_ERR_ARG, "dof_idx[%d] out of range", b); }
     t.dof_idx[b] = dof_idx[b];
     t.depth[b] = (short)depth[b];
     int c = b;
     for (int d = depth[b]; d >= 0; d--) { t.chain[b * maxd + d] = (short)c; c = parent[c]; }
-    for (int a = 0; a < 3; a++) { t.local_t[3 * b + a] = local_t[3 * b + a]; t.axis[3 * b + a] = axis[3 * b + a]; }
+    // normalize(axis) = axis / max(|axis|, 1e-9) in float64 (torch_utils.py:57-59), once
+    double an = sqrt(axis[3 * b] * axis[3 * b] + axis[3 * b + 1] * axis[3 * b + 1] + axis[3 * b + 2] * axis[3 * b + 2]);
+    if (an < 1e-9) an = 1e-9;
+    for (int a = 0; a < 3; a++) { t.local_t[3 * b + a] = local_t[3 * b + a]; t.axis[3 * b + a] = axis[3 * b + a] / an; }
     for (int a = 0; a < 4; a++) t.local_r[4 * b + a] = local_r[4 * b + a];
   }
   hipError_t e;
@@ -361,7 +375,7 @@ int gmr_fk_batch_dev(gmr_fk_t* k, int B, const float* d_root_pos, const float* d
       k->min_part_cap = blocks;
     }
   }
-  HIP_TRY(gmr_launch_fk_batch(k->d_tree, k->tree.nbody, k->tree.maxd, B, d_root_pos, d_root_rot, d_dof, d_body_pos,
+  HIP_TRY(gmr_launch_fk_batch(k->d_tree, k->tree.nbody, k->tree.nslot, B, d_root_pos, d_root_rot, d_dof, d_body_pos,
                               d_body_rot, k->d_min_part, d_min_z, (hipStream_t)stream));
   return GMR_OK;
 }

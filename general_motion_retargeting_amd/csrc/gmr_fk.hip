@@ -2,21 +2,32 @@
 //
 // Replaces KinematicsModel.forward_kinematics (reference kinematics_model.py:213-246), which on the
 // reference's "cuda:0" path is ~70 tiny ATen launches per body (~2.6k per call), by one kernel.
-// This one IS bandwidth-shaped: 4*ndof B in, 12*nbody (+16*nbody) B out per frame.
+// This one IS bandwidth-shaped: 4*ndof + 28 B in, 12*nbody (+16*nbody) B out per frame.
 //
-// Lane mapping: thread = (frame, body), bodies of a frame on consecutive lanes, frames of a block
-// consecutive, so body_pos[f][b][0..2] / body_rot[f][b][0..3] stores are perfectly coalesced
-// (consecutive lanes write consecutive 12 B / 16 B chunks).  Each lane first forms its own body's
-// joint-composed local rotation (local_rot * axis_angle(dof)) into LDS, then walks root -> body
-// reading its ancestors' local rotations from LDS.  The walk repeats, per lane, exactly the
-// operation sequence of the reference's serial loop (pos_j = pos_p + rot_p * t_j;
-// rot_j = rot_p * (r_j * jr_j)), so the redundancy changes no rounding.
+// Lane mapping: one lane per FRAME, bodies visited in the tree's DFS order by the whole wave
+// (wave-uniform control flow, no divergence).  In DFS order a body's first child follows it
+// immediately, so the parent transform is usually still in registers; only bodies with two or more
+// children are parked in LDS slots [slot][component][lane] (conflict-free; 2-3 slots for a humanoid)
+// and reloaded when a later child comes up.  The serial order per frame is exactly the reference's
+// (pos_j = pos_p + rot_p * t_j;
+// rot_j = rot_p * (r_j * jr_j)), hence the same rounding sequence as its float32 loop.
+// Stores: a lane's pieces (12 B of body j) are 456 B apart from its neighbour's, and ~100k frames are
+// in flight chip-wide, more than L2 can hold until a line is complete -- written straight from
+// registers they reach HBM as partial lines (measured 0.9 TB/s).  The positions-only variant (all the
+// dataset scripts consume, smplx_to_robot_dataset.py:110,121) therefore stages the wave's 64 x 456 B
+// = 29 KB output block in LDS in its final layout and streams it out with contiguous 16 B-per-lane
+// stores, every line written once and whole.  With rotations requested the direct stores are kept.
+// The dof row of a frame (116 B) is read element by element but stays L1-resident across the walk.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
 
 #include "../../include/gmr_hip.h"
 #include "gmr_fk_tree.h"
+
+// float32 arithmetic here mirrors torch eager ops (one rounding per operation): no FMA contraction,
+// which also makes both template variants produce the same bits
+#pragma clang fp contract(off)
 
 namespace gmr {
 
@@ -41,74 +52,130 @@ __device__ __forceinline__ void qrot_xyzw(f4 q, float vx, float vy, float vz, fl
   oz = vz * s + cz * q.w * 2.0f + q.z * d * 2.0f;
 }
 
-__global__ __launch_bounds__(256) void fk_batch_kernel(const FkTree* __restrict__ tree, int B,
-                                                       const float* __restrict__ root_pos,
-                                                       const float* __restrict__ root_rot,
-                                                       const float* __restrict__ dof,
-                                                       float* __restrict__ body_pos, float* __restrict__ body_rot,
-                                                       float* __restrict__ min_part) {
-  extern __shared__ __align__(16) float fsm[];
-  const int nb = tree->nbody, ndof = tree->ndof, maxd = tree->maxd;
-  const int fpb = 256 / nb;
-  float* cr = fsm;                        // [fpb][nb][4]
-  float* lt = cr + fpb * nb * 4;          // [nb][3]
-  short* chain = reinterpret_cast<short*>(lt + nb * 3);  // [nb][maxd]
-  short* depth = chain + nb * maxd;       // [nb]
-  __shared__ float red[4];
+constexpr int FK_BLOCK = 64;  // one wave per block
+
+template <bool STAGED>
+__global__ __launch_bounds__(FK_BLOCK) void fk_batch_kernel(const FkTree* __restrict__ tree, int B,
+                                                            const float* __restrict__ root_pos,
+                                                            const float* __restrict__ root_rot,
+                                                            const float* __restrict__ dof,
+                                                            float* __restrict__ body_pos,
+                                                            float* __restrict__ body_rot,
+                                                            float* __restrict__ min_part) {
+  extern __shared__ __align__(16) float fsm[];  // slots [nslot][7][FK_BLOCK], then (STAGED) pos [FK_BLOCK][nb*3], rot [FK_BLOCK][nb*4]
+  __shared__ float red[FK_BLOCK / 64];
+  const int nb = tree->nbody, ndof = tree->ndof;
   const int tid = threadIdx.x;
-  for (int i = tid; i < nb * 3; i += 256) lt[i] = tree->local_t[i];
-  for (int i = tid; i < nb * maxd; i += 256) chain[i] = tree->chain[i];
-  for (int i = tid; i < nb; i += 256) depth[i] = tree->depth[i];
-  const int fl = tid / nb, b = tid - fl * nb;
-  const long long f = (long long)blockIdx.x * fpb + fl;
-  const bool on = fl < fpb && f < B;
-  if (on && b > 0) {
-    // dof_to_rot: sin/cos of the float32 half angle; products and normalisation in float64;
-    // rounded to float32 on assignment (kinematics_model.py:21-36, torch_utils.py:353-359)
-    f4 jr = {0.f, 0.f, 0.f, 1.f};
-    int di = tree->dof_idx[b];
-    if (di >= 0) {
-      float th = dof[f * ndof + di] / 2.0f;
-      double s = (double)sinf(th), c = (double)cosf(th);
-      double ax = tree->axis[3 * b], ay = tree->axis[3 * b + 1], az = tree->axis[3 * b + 2];
-      double an = fmax(sqrt(ax * ax + ay * ay + az * az), 1e-9);
-      double qx = ax / an * s, qy = ay / an * s, qz = az / an * s, qw = c;
-      double qn = fmax(sqrt(qx * qx + qy * qy + qz * qz + qw * qw), 1e-9);
-      jr = f4{(float)(qx / qn), (float)(qy / qn), (float)(qz / qn), (float)(qw / qn)};
+  const long long f = (long long)blockIdx.x * FK_BLOCK + tid;
+  const bool on = f < B;
+  const long long fc = on ? f : 0;
+  float* stk = fsm + tid;
+  const int row = nb * 3;
+  float* outb = fsm + tree->nslot * 7 * FK_BLOCK;  // used when STAGED
+  float* outr = outb + FK_BLOCK * row;             // used when STAGED and body_rot
+  const int rrow = nb * 4;
+  float zmin = INFINITY;
+  float cpx, cpy, cpz;   // transform of the body visited last (the parent of a first child)
+  f4 crot;
+  {
+    float px = root_pos[fc * 3], py = root_pos[fc * 3 + 1], pz = root_pos[fc * 3 + 2];
+    f4 rot = {root_rot[fc * 4], root_rot[fc * 4 + 1], root_rot[fc * 4 + 2], root_rot[fc * 4 + 3]};
+    cpx = px; cpy = py; cpz = pz; crot = rot;
+    if (tree->save_slot[0] >= 0) {
+      float* sl = stk + tree->save_slot[0] * 7 * FK_BLOCK;
+      sl[0] = px; sl[FK_BLOCK] = py; sl[2 * FK_BLOCK] = pz;
+      sl[3 * FK_BLOCK] = rot.x; sl[4 * FK_BLOCK] = rot.y; sl[5 * FK_BLOCK] = rot.z; sl[6 * FK_BLOCK] = rot.w;
     }
-    f4 lr = {tree->local_r[4 * b], tree->local_r[4 * b + 1], tree->local_r[4 * b + 2], tree->local_r[4 * b + 3]};
-    f4 c = qmul_xyzw(lr, jr);
-    float* o = cr + (fl * nb + b) * 4;
-    o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w;
+    if (STAGED) {
+      float* o = outb + tid * row;
+      o[0] = px; o[1] = py; o[2] = pz;
+      if (body_rot) { float* r = outr + tid * rrow; r[0] = rot.x; r[1] = rot.y; r[2] = rot.z; r[3] = rot.w; }
+      if (on) zmin = pz;
+    } else if (on) {
+      float* op = body_pos + f * nb * 3;
+      op[0] = px; op[1] = py; op[2] = pz;
+      if (body_rot) *reinterpret_cast<float4*>(body_rot + f * nb * 4) = make_float4(rot.x, rot.y, rot.z, rot.w);
+      zmin = pz;
+    }
   }
-  __syncthreads();
-  float z = INFINITY;
-  if (on) {
-    float px = root_pos[f * 3], py = root_pos[f * 3 + 1], pz = root_pos[f * 3 + 2];
-    f4 rot = {root_rot[f * 4], root_rot[f * 4 + 1], root_rot[f * 4 + 2], root_rot[f * 4 + 3]};
-    const int dep = depth[b];
-    const short* ch = chain + b * maxd;
-    for (int d = 1; d <= dep; d++) {
-      int c = ch[d];
-      float wx, wy, wz;
-      qrot_xyzw(rot, lt[3 * c], lt[3 * c + 1], lt[3 * c + 2], wx, wy, wz);
-      px = px + wx; py = py + wy; pz = pz + wz;
-      const float* cc = cr + (fl * nb + c) * 4;
-      rot = qmul_xyzw(rot, f4{cc[0], cc[1], cc[2], cc[3]});
+  const float* drow = dof + fc * ndof;
+  for (int j = 1; j < nb; j++) {
+    // wave-uniform tree data (scalar loads)
+    const int src = tree->load_slot[j], dst = tree->save_slot[j];
+    const int di = tree->dof_idx[j];
+    const float tx = tree->local_t[3 * j], ty = tree->local_t[3 * j + 1], tz = tree->local_t[3 * j + 2];
+    f4 lr = {tree->local_r[4 * j], tree->local_r[4 * j + 1], tree->local_r[4 * j + 2], tree->local_r[4 * j + 3]};
+    f4 cr = lr;
+    if (di >= 0) {
+      // dof_to_rot: sin/cos of the float32 half angle; products and the normalisation in float64;
+      // rounded to float32 on assignment (kinematics_model.py:21-36, torch_utils.py:353-359).
+      // tree->axis holds normalize(axis) (float64, computed once on the host).
+      float th = drow[di] / 2.0f;
+      float sf, cf;
+      sincosf(th, &sf, &cf);
+      double s = (double)sf, c = (double)cf;
+      double qx = tree->axis[3 * j] * s, qy = tree->axis[3 * j + 1] * s, qz = tree->axis[3 * j + 2] * s, qw = c;
+      // quat_unit in float64: x / |q|.  |q| is 1 to float32 rounding, so x * rsqrt(|q|^2) rounds to the
+      // same float32 as x / sqrt(|q|^2) (they differ by <= 2 ulp of float64)
+      double rn = rsqrt(fmax(qx * qx + qy * qy + qz * qz + qw * qw, 1e-18));
+      f4 jr = {(float)(qx * rn), (float)(qy * rn), (float)(qz * rn), (float)(qw * rn)};
+      cr = qmul_xyzw(lr, jr);
+    }  // no joint: r_j * (0,0,0,1) == r_j exactly
+    float ppx = cpx, ppy = cpy, ppz = cpz;
+    f4 prot = crot;
+    if (src >= 0) {   // wave-uniform: this body is not the first child of the body before it
+      const float* par = stk + src * 7 * FK_BLOCK;
+      ppx = par[0]; ppy = par[FK_BLOCK]; ppz = par[2 * FK_BLOCK];
+      prot = f4{par[3 * FK_BLOCK], par[4 * FK_BLOCK], par[5 * FK_BLOCK], par[6 * FK_BLOCK]};
     }
-    float* op = body_pos + (f * nb + b) * 3;
-    op[0] = px; op[1] = py; op[2] = pz;
+    float wx, wy, wz;
+    qrot_xyzw(prot, tx, ty, tz, wx, wy, wz);
+    float px = ppx + wx, py = ppy + wy, pz = ppz + wz;
+    f4 rot = qmul_xyzw(prot, cr);
+    cpx = px; cpy = py; cpz = pz; crot = rot;
+    if (dst >= 0) {
+      float* cur = stk + dst * 7 * FK_BLOCK;
+      cur[0] = px; cur[FK_BLOCK] = py; cur[2 * FK_BLOCK] = pz;
+      cur[3 * FK_BLOCK] = rot.x; cur[4 * FK_BLOCK] = rot.y; cur[5 * FK_BLOCK] = rot.z; cur[6 * FK_BLOCK] = rot.w;
+    }
+    if (STAGED) {
+      float* o = outb + tid * row + 3 * j;
+      o[0] = px; o[1] = py; o[2] = pz;
+      if (body_rot) { float* r = outr + tid * rrow + 4 * j; r[0] = rot.x; r[1] = rot.y; r[2] = rot.z; r[3] = rot.w; }
+      if (on) zmin = fminf(zmin, pz);
+    } else if (on) {
+      float* op = body_pos + (f * nb + j) * 3;
+      op[0] = px; op[1] = py; op[2] = pz;
+      if (body_rot) *reinterpret_cast<float4*>(body_rot + (f * nb + j) * 4) = make_float4(rot.x, rot.y, rot.z, rot.w);
+      zmin = fminf(zmin, pz);
+    }
+  }
+  if (STAGED) {
+    // the block's output is one contiguous range of body_pos: stream it out 16 B per lane
+    __syncthreads();
+    const long long f0 = (long long)blockIdx.x * FK_BLOCK;
+    const long long nfr = (B - f0) < FK_BLOCK ? (B - f0) : FK_BLOCK;
+    const int nfloat = (int)(nfr * row);
+    float* gdst = body_pos + f0 * row;
+    const int nvec = nfloat >> 2;
+    for (int i = tid; i < nvec; i += FK_BLOCK)
+      reinterpret_cast<float4*>(gdst)[i] = reinterpret_cast<const float4*>(outb)[i];
+    for (int i = (nvec << 2) + tid; i < nfloat; i += FK_BLOCK) gdst[i] = outb[i];
     if (body_rot) {
-      float4* orr = reinterpret_cast<float4*>(body_rot + (f * nb + b) * 4);
-      *orr = make_float4(rot.x, rot.y, rot.z, rot.w);
+      float4* rdst = reinterpret_cast<float4*>(body_rot + f0 * rrow);
+      const int nrv = (int)(nfr * nb);
+      for (int i = tid; i < nrv; i += FK_BLOCK) rdst[i] = reinterpret_cast<const float4*>(outr)[i];
     }
-    z = pz;
   }
   if (min_part) {
-    for (int off = 32; off > 0; off >>= 1) z = fminf(z, __shfl_xor(z, off, 64));
-    if ((tid & 63) == 0) red[tid >> 6] = z;
+    for (int off = 32; off > 0; off >>= 1) zmin = fminf(zmin, __shfl_xor(zmin, off, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = zmin;
     __syncthreads();
-    if (tid == 0) min_part[blockIdx.x] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+    if (tid == 0) {
+      float m = red[0];
+      for (int i = 1; i < FK_BLOCK / 64; i++) m = fminf(m, red[i]);
+      min_part[blockIdx.x] = m;
+    }
   }
 }
 
@@ -125,22 +192,37 @@ __global__ __launch_bounds__(256) void min_reduce_kernel(const float* __restrict
 }  // namespace gmr
 
 extern "C" int gmr_fk_blocks(int nbody, int B) {
-  int fpb = 256 / nbody;
-  return (B + fpb - 1) / fpb;
+  (void)nbody;
+  return (B + gmr::FK_BLOCK - 1) / gmr::FK_BLOCK;
 }
 
-extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree* d_tree, int nbody, int maxd, int B,
+extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree* d_tree, int nbody, int nslot, int B,
                                           const float* d_root_pos, const float* d_root_rot, const float* d_dof,
                                           float* d_body_pos, float* d_body_rot, float* d_min_part, float* d_min_z,
                                           hipStream_t stream) {
   if (B <= 0) return hipSuccess;
-  int fpb = 256 / nbody;
-  int blocks = (B + fpb - 1) / fpb;
-  size_t smem = (size_t)fpb * nbody * 4 * sizeof(float) + (size_t)nbody * 3 * sizeof(float) +
-                (size_t)nbody * maxd * sizeof(short) + (size_t)nbody * sizeof(short);
-  smem = (smem + 15) / 16 * 16;
-  hipLaunchKernelGGL(gmr::fk_batch_kernel, dim3(blocks), dim3(256), smem, stream, d_tree, B, d_root_pos,
-                     d_root_rot, d_dof, d_body_pos, d_body_rot, d_min_z ? d_min_part : nullptr);
+  int blocks = gmr_fk_blocks(nbody, B);
+  size_t smem = (size_t)nslot * 7 * gmr::FK_BLOCK * sizeof(float);
+  // 16-B aligned destinations: LDS-staged, fully coalesced output
+  // (the block strides FK_BLOCK * nbody * 12 B and * 16 B are multiples of 16)
+  const size_t stage_bytes = (size_t)gmr::FK_BLOCK * nbody * (d_body_rot ? 7 : 3) * sizeof(float);
+  const bool staged = (reinterpret_cast<uintptr_t>(d_body_pos) & 15u) == 0 &&
+                      (reinterpret_cast<uintptr_t>(d_body_rot) & 15u) == 0 && smem + stage_bytes <= 160 * 1024 - 1024;
+  if (staged) {
+    smem += stage_bytes;
+    static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in once per process
+    if (!attr_set) {
+      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(gmr::fk_batch_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+      if (ea != hipSuccess) return ea;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(gmr::fk_batch_kernel<true>, dim3(blocks), dim3(gmr::FK_BLOCK), smem, stream, d_tree, B,
+                       d_root_pos, d_root_rot, d_dof, d_body_pos, d_body_rot, d_min_z ? d_min_part : nullptr);
+  } else {
+    hipLaunchKernelGGL(gmr::fk_batch_kernel<false>, dim3(blocks), dim3(gmr::FK_BLOCK), smem, stream, d_tree, B,
+                       d_root_pos, d_root_rot, d_dof, d_body_pos, d_body_rot, d_min_z ? d_min_part : nullptr);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (d_min_z) {
@@ -149,3 +231,4 @@ extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree* d_tree, int nbody, 
   }
   return e;
 }
+

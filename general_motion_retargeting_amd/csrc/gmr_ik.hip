@@ -271,26 +271,55 @@ __device__ __forceinline__ void build_qp_wave(const IkLayout& L, double* sm, int
   }
   PROF_END(pr, PH_CVEC);
   PROF_BEGIN(pr);
-  // (d) H: every lane sums the terms of the entries it owns (static schedule) and stores each once
+  // (d) H: every lane sums the terms of the entries it owns (static schedule) and stores each once.
+  // Two terms per trip, operands of both loaded before any store (Jw is read-only here, H write-only).
   {
-    double* H = sm + L.H;
+    double* __restrict__ H = sm + L.H;
+    const double* __restrict__ J = sm + L.Jw;
     const double diag = damping + mu;
     const int i1 = istart[lane + 1];
     int it = istart[lane];
     double acc = 0.0;
-    uint32_t w = it < i1 ? items[it] : 0u;
-    while (it < i1) {
-      uint32_t wn = (it + 1 < i1) ? items[it + 1] : 0u;
-      if (!((w >> 30) & 1u)) acc += dot6(Jw + 6 * (w & 511u), Jw + 6 * ((w >> 9) & 511u));
-      if (w >> 31) {
-        int da = (w >> 18) & 63u, db = (w >> 24) & 63u;
+    for (; it + 1 < i1; it += 2) {
+      const uint32_t w0 = items[it], w1 = items[it + 1];
+      const double* a0 = J + 6 * (w0 & 511u);
+      const double* b0 = J + 6 * ((w0 >> 9) & 511u);
+      const double* a1 = J + 6 * (w1 & 511u);
+      const double* b1 = J + 6 * ((w1 >> 9) & 511u);
+      double x0[6], y0[6], x1[6], y1[6];
+#pragma unroll
+      for (int r = 0; r < 6; r++) { x0[r] = a0[r]; y0[r] = b0[r]; x1[r] = a1[r]; y1[r] = b1[r]; }
+      double s0 = (x0[0] * y0[0] + x0[1] * y0[1] + x0[2] * y0[2]) + (x0[3] * y0[3] + x0[4] * y0[4] + x0[5] * y0[5]);
+      double s1 = (x1[0] * y1[0] + x1[1] * y1[1] + x1[2] * y1[2]) + (x1[3] * y1[3] + x1[4] * y1[4] + x1[5] * y1[5]);
+      if ((w0 >> 30) & 1u) s0 = 0.0;
+      if ((w1 >> 30) & 1u) s1 = 0.0;
+      acc += s0;
+      if (w0 >> 31) {
+        int da = (w0 >> 18) & 63u, db = (w0 >> 24) & 63u;
         double v = acc + (da == db ? diag : 0.0);
         H[da * ldh + db] = v;
         H[db * ldh + da] = v;
         acc = 0.0;
       }
-      w = wn;
-      it++;
+      acc += s1;
+      if (w1 >> 31) {
+        int da = (w1 >> 18) & 63u, db = (w1 >> 24) & 63u;
+        double v = acc + (da == db ? diag : 0.0);
+        H[da * ldh + db] = v;
+        H[db * ldh + da] = v;
+        acc = 0.0;
+      }
+    }
+    if (it < i1) {
+      const uint32_t w0 = items[it];
+      double s0 = ((w0 >> 30) & 1u) ? 0.0 : dot6(J + 6 * (w0 & 511u), J + 6 * ((w0 >> 9) & 511u));
+      acc += s0;
+      if (w0 >> 31) {
+        int da = (w0 >> 18) & 63u, db = (w0 >> 24) & 63u;
+        double v = acc + (da == db ? diag : 0.0);
+        H[da * ldh + db] = v;
+        H[db * ldh + da] = v;
+      }
     }
   }
   WSYNC();
@@ -443,21 +472,18 @@ __device__ __forceinline__ void integrate_wave(const IkLayout& L, double* sm, do
   double* q = sm + L.q;
   const double* dq = sm + L.x;
   if (lane == 0) {
-    double v[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) v[i] = dq[i] / dt;
-    q[0] += dt * v[0]; q[1] += dt * v[1]; q[2] += dt * v[2];
-    double n = sqrt(v[3] * v[3] + v[4] * v[4] + v[5] * v[5]);
+    // v = dq / dt followed by dt * v (solve_ik / mj_integratePos) is dq to 1 ulp: integrate dq directly
+    q[0] += dq[0]; q[1] += dq[1]; q[2] += dq[2];
+    double n2 = dq[3] * dq[3] + dq[4] * dq[4] + dq[5] * dq[5];
     d4 quat = qnormalize(d4{q[3], q[4], q[5], q[6]});
-    if (n >= 1e-15) {
-      double inv = 1.0 / n;
-      double ang = dt * n;
-      if (ang != 0.0) quat = qmul(quat, axis_angle(d3{v[3] * inv, v[4] * inv, v[5] * inv}, ang));
+    if (n2 >= 1e-30 * dt * dt) {
+      double inv = rsqrt(n2);
+      double ang = n2 * inv;
+      quat = qmul(quat, axis_angle(d3{dq[3] * inv, dq[4] * inv, dq[5] * inv}, ang));
     }
     q[3] = quat.w; q[4] = quat.x; q[5] = quat.y; q[6] = quat.z;
   } else if (lane >= 6 && lane < L.nv) {
-    double v = dq[lane] / dt;
-    q[7 + lane - 6] += dt * v;
+    q[7 + lane - 6] += dq[lane];
   }
   WSYNC();
   PROF_END(pr, PH_INTEG);
