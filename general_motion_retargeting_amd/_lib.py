@@ -105,15 +105,17 @@ class DeviceBuffer:
     def from_host(cls, a: np.ndarray, stream=None) -> "DeviceBuffer":
         a = np.ascontiguousarray(a)
         b = cls(a.nbytes)
-        check(lib().gmr_memcpy_h2d(b.ptr, _ptr(a), a.nbytes, stream))
-        check(lib().gmr_stream_sync(stream))
+        s = stream.ptr if isinstance(stream, Stream) else stream
+        check(lib().gmr_memcpy_h2d(b.ptr, _ptr(a), a.nbytes, s))
+        check(lib().gmr_stream_sync(s))
         return b
 
     def to_host(self, shape, dtype, stream=None) -> np.ndarray:
         out = np.empty(shape, dtype=dtype)
         assert out.nbytes <= self.nbytes
-        check(lib().gmr_memcpy_d2h(_ptr(out), self.ptr, out.nbytes, stream))
-        check(lib().gmr_stream_sync(stream))
+        s = stream.ptr if isinstance(stream, Stream) else stream
+        check(lib().gmr_memcpy_d2h(_ptr(out), self.ptr, out.nbytes, s))
+        check(lib().gmr_stream_sync(s))
         return out
 
     def free(self):
@@ -124,6 +126,25 @@ class DeviceBuffer:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+class Stream:
+    """Non-blocking HIP stream (gmr_stream_create)."""
+
+    def __init__(self):
+        p = C.c_void_p()
+        check(lib().gmr_stream_create(C.byref(p)))
+        self.ptr = p
+
+    def sync(self):
+        check(lib().gmr_stream_sync(self.ptr))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().gmr_stream_destroy(self.ptr)
         except Exception:
             pass
 
@@ -193,8 +214,9 @@ class Solver:
         """Device pointers (DeviceBuffer or raw c_void_p); asynchronous on `stream`."""
         def p(x):
             return x.ptr if isinstance(x, DeviceBuffer) else x
+        s = stream.ptr if isinstance(stream, Stream) else stream
         check(lib().gmr_retarget_streams_dev(self.handle, int(S), int(T), p(d_q0), p(d_human), p(d_len), int(flags),
-                                             p(d_q_out), p(d_nsolve), p(d_status), stream))
+                                             p(d_q_out), p(d_nsolve), p(d_status), s))
 
     def close(self):
         if self.handle:

@@ -18,10 +18,9 @@ static_assert(sizeof(gmr_taskset_t) % 8 == 0, "gmr_taskset_t must be 8-byte size
 static_assert(offsetof(gmr_model_t, timestep) % 8 == 0, "double block of gmr_model_t misaligned");
 static_assert(offsetof(gmr_taskset_t, damping) % 8 == 0, "double block of gmr_taskset_t misaligned");
 
-extern "C" hipError_t gmr_launch_ik_streams(const gmr_model_t*, const gmr_taskset_t*, const uint32_t*,
-                                            const gmr::IkLayout*, int, int, const double*, const double*,
-                                            const int32_t*, int, double*, int32_t*, int32_t*, hipStream_t,
-                                            unsigned long long*);
+extern "C" hipError_t gmr_launch_ik_streams(const uint4*, const gmr::IkLayout*, const gmr::IkParams*, int, int,
+                                            const double*, const double*, const int32_t*, int, double*, int32_t*,
+                                            int32_t*, hipStream_t, unsigned long long*);
 extern "C" hipError_t gmr_ik_set_max_smem(int nvp, int bytes);
 extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree*, int, int, int, const float*, const float*, const float*,
                                           float*, float*, float*, float*, hipStream_t);
@@ -47,9 +46,12 @@ struct gmr_solver {
   gmr_model_t model;
   gmr_taskset_t ts;
   gmr::IkLayout layout;
-  gmr_model_t* d_model = nullptr;
-  gmr_taskset_t* d_ts = nullptr;
-  uint32_t* d_sched = nullptr;   // static H-assembly schedule (gmr_ik_layout.h)
+  gmr::IkParams params;
+  uint4* d_image = nullptr;      // host-built LDS image of the constants (gmr_ik_layout.h)
+  char* ws = nullptr;            // grow-only device workspace of the host-buffer entry point
+  size_t ws_bytes = 0;
+  char* pin = nullptr;           // pinned host staging for small calls (one H2D + one D2H per call)
+  static constexpr size_t kPinBytes = 1u << 20;
 };
 
 struct gmr_fk {
@@ -137,7 +139,7 @@ static int validate(const gmr_model_t* m, const gmr_taskset_t* t) {
   if (t->magic != GMR_MAGIC_TASKSET || t->version != GMR_ABI_VERSION) return fail(GMR_ERR_ARG, "bad taskset blob");
   if (m->nbody < 1 || m->nbody > GMR_MAX_BODIES || m->nbody > 64) return fail(GMR_ERR_ARG, "nbody out of range");
   if (m->nhinge < 0 || m->nhinge > GMR_MAX_HINGES) return fail(GMR_ERR_ARG, "nhinge out of range");
-  if (m->nv != m->nhinge + 6 || m->nq != m->nhinge + 7 || m->nv > 64) return fail(GMR_ERR_ARG, "nq/nv inconsistent");
+  if (m->nv != m->nhinge + 6 || m->nq != m->nhinge + 7 || m->nv > GMR_MAX_DOF) return fail(GMR_ERR_ARG, "nq/nv inconsistent");
   if (!(m->timestep > 0.0)) return fail(GMR_ERR_ARG, "timestep must be positive");
   if (m->parent[0] != -1) return fail(GMR_ERR_ARG, "body 0 must be the root");
   for (int b = 1; b < m->nbody; b++) {
@@ -189,26 +191,17 @@ int gmr_solver_create(const gmr_model_t* model, const gmr_taskset_t* taskset, gm
   if (!s) return fail(GMR_ERR_ARG, "out of host memory");
   s->model = *model;
   s->ts = *taskset;
-  if (gmr::ik_padded_nv(s->model.nv) < 0) { delete s; return fail(GMR_ERR_ARG, "nv = %d > 36 is not supported", s->model.nv); }
+  if (gmr::ik_padded_nv(s->model.nv) < 0) { delete s; return fail(GMR_ERR_ARG, "nv = %d > 48 is not supported", s->model.nv); }
   gmr::IkSchedule sch = gmr::make_ik_schedule(s->model, s->ts);
   s->layout = gmr::make_ik_layout(s->model, s->ts, sch);
   if (s->layout.smem_bytes > 160 * 1024) { delete s; return fail(GMR_ERR_ARG, "robot too large for LDS"); }
-  std::vector<uint32_t> words((size_t)s->layout.n_word, 0u);
-  for (int st = 0; st < 2; st++) {
-    for (size_t i = 0; i < sch.items[st].size(); i++) words[s->layout.w_items[st] + i] = sch.items[st][i];
-    for (int l = 0; l < 65; l++) words[s->layout.w_istart[st] + l] = (uint32_t)sch.istart[st][l];
-  }
+  s->params = gmr::make_ik_params(s->model, s->ts);
+  std::vector<char> img = gmr::make_ik_image(s->model, s->ts, sch, s->layout);
   hipError_t e;
-  if ((e = hipMalloc((void**)&s->d_model, sizeof(gmr_model_t))) != hipSuccess ||
-      (e = hipMalloc((void**)&s->d_ts, sizeof(gmr_taskset_t))) != hipSuccess ||
-      (e = hipMalloc((void**)&s->d_sched, words.size() * sizeof(uint32_t) + 8)) != hipSuccess ||
-      (e = hipMemcpy(s->d_model, &s->model, sizeof(gmr_model_t), hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = hipMemcpy(s->d_ts, &s->ts, sizeof(gmr_taskset_t), hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = hipMemcpy(s->d_sched, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess ||
+  if ((e = hipMalloc((void**)&s->d_image, img.size())) != hipSuccess ||
+      (e = hipMemcpy(s->d_image, img.data(), img.size(), hipMemcpyHostToDevice)) != hipSuccess ||
       (e = gmr_ik_set_max_smem(s->layout.nvp, s->layout.smem_bytes)) != hipSuccess) {
-    if (s->d_model) (void)hipFree(s->d_model);
-    if (s->d_ts) (void)hipFree(s->d_ts);
-    if (s->d_sched) (void)hipFree(s->d_sched);
+    if (s->d_image) (void)hipFree(s->d_image);
     delete s;
     return fail(GMR_ERR_HIP, "gmr_solver_create: %s", hipGetErrorString(e));
   }
@@ -218,9 +211,9 @@ int gmr_solver_create(const gmr_model_t* model, const gmr_taskset_t* taskset, gm
 
 int gmr_solver_destroy(gmr_solver_t* s) {
   if (!s) return GMR_OK;
-  (void)hipFree(s->d_model);
-  (void)hipFree(s->d_ts);
-  (void)hipFree(s->d_sched);
+  (void)hipFree(s->d_image);
+  if (s->ws) (void)hipFree(s->ws);
+  if (s->pin) (void)hipHostFree(s->pin);
   delete s;
   return GMR_OK;
 }
@@ -242,8 +235,8 @@ int gmr_retarget_streams_dev(gmr_solver_t* s, int S, int T, const double* d_q0, 
   if (S < 0 || T < 0) return fail(GMR_ERR_ARG, "negative S/T");
   if (S == 0 || T == 0) return GMR_OK;
   if (!d_q0 || !d_human || !d_q_out || !d_nsolve || !d_status) return fail(GMR_ERR_ARG, "null device buffer");
-  HIP_TRY(gmr_launch_ik_streams(s->d_model, s->d_ts, s->d_sched, &s->layout, S, T, d_q0, d_human, d_len, flags,
-                                d_q_out, d_nsolve, d_status, (hipStream_t)stream, nullptr));
+  HIP_TRY(gmr_launch_ik_streams(s->d_image, &s->layout, &s->params, S, T, d_q0, d_human, d_len, flags, d_q_out,
+                                d_nsolve, d_status, (hipStream_t)stream, nullptr));
   return GMR_OK;
 }
 
@@ -251,8 +244,8 @@ int gmr_retarget_streams_dev(gmr_solver_t* s, int S, int T, const double* d_q0, 
 // diagnostic builds only (tools/phase_profile.py): per-stream phase cycle counters
 int gmr_retarget_streams_prof(gmr_solver_t* s, int S, int T, const double* d_q0, const double* d_human, int flags,
                               double* d_q_out, int32_t* d_nsolve, int32_t* d_status, unsigned long long* d_prof) {
-  HIP_TRY(gmr_launch_ik_streams(s->d_model, s->d_ts, s->d_sched, &s->layout, S, T, d_q0, d_human, nullptr, flags,
-                                d_q_out, d_nsolve, d_status, nullptr, d_prof));
+  HIP_TRY(gmr_launch_ik_streams(s->d_image, &s->layout, &s->params, S, T, d_q0, d_human, nullptr, flags, d_q_out,
+                                d_nsolve, d_status, nullptr, d_prof));
   return GMR_OK;
 }
 #endif
@@ -266,32 +259,60 @@ int gmr_retarget_streams(gmr_solver_t* s, int S, int T, const double* q0, const 
   const size_t nq = s->model.nq, nh = s->ts.nhuman;
   const size_t b_q0 = (size_t)S * nq * 8, b_h = (size_t)S * T * nh * 7 * 8, b_qo = (size_t)S * T * nq * 8;
   const size_t b_ns = (size_t)S * T * 2 * 4, b_st = (size_t)S * 4, b_len = (size_t)S * 4;
-  char* d = nullptr;
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-  size_t o_q0 = 0, o_h = o_q0 + up(b_q0), o_qo = o_h + up(b_h), o_ns = o_qo + up(b_qo), o_st = o_ns + up(b_ns),
-         o_len = o_st + up(b_st), total = o_len + up(b_len);
-  HIP_TRY(hipMalloc((void**)&d, total));
+  size_t o_q0 = 0, o_h = o_q0 + up(b_q0), o_len = o_h + up(b_h), o_qo = o_len + up(b_len), o_ns = o_qo + up(b_qo),
+         o_st = o_ns + up(b_ns), total = o_st + up(b_st);
+  // grow-only workspace kept on the handle: a per-frame caller (retarget() once per frame) pays no
+  // hipMalloc/hipFree per call.  Like the reference object, a handle is not re-entrant on this path.
+  if (total > s->ws_bytes) {
+    if (s->ws) (void)hipFree(s->ws);
+    s->ws = nullptr;
+    s->ws_bytes = 0;
+    size_t want = total < (1u << 20) ? (1u << 20) : total;
+    HIP_TRY(hipMalloc((void**)&s->ws, want));
+    s->ws_bytes = want;
+  }
+  char* d = s->ws;
   int rc = GMR_OK;
   hipError_t e;
-  if ((e = hipMemcpy(d + o_q0, q0, b_q0, hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = hipMemcpy(d + o_h, human, b_h, hipMemcpyHostToDevice)) != hipSuccess ||
-      (len && (e = hipMemcpy(d + o_len, len, b_len, hipMemcpyHostToDevice)) != hipSuccess)) {
+  // inputs are laid out [q0 | human | len | q_out | nsolve | status]; small calls (the per-frame
+  // API) go through pinned staging so that a call is 1 H2D + 1 launch + 1 D2H + 1 sync
+  const size_t in_bytes = o_qo, out_bytes = total - o_qo;
+  const bool small = total <= gmr_solver::kPinBytes;
+  if (small && !s->pin) HIP_TRY(hipHostMalloc((void**)&s->pin, gmr_solver::kPinBytes, hipHostMallocDefault));
+  if (small) {
+    memcpy(s->pin + o_q0, q0, b_q0);
+    memcpy(s->pin + o_h, human, b_h);
+    if (len) memcpy(s->pin + o_len, len, b_len);
+    if ((e = hipMemcpyAsync(d, s->pin, in_bytes, hipMemcpyHostToDevice, nullptr)) != hipSuccess)
+      rc = fail(GMR_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
+  } else if ((e = hipMemcpyAsync(d + o_q0, q0, b_q0, hipMemcpyHostToDevice, nullptr)) != hipSuccess ||
+             (e = hipMemcpyAsync(d + o_h, human, b_h, hipMemcpyHostToDevice, nullptr)) != hipSuccess ||
+             (len && (e = hipMemcpyAsync(d + o_len, len, b_len, hipMemcpyHostToDevice, nullptr)) != hipSuccess)) {
     rc = fail(GMR_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
   }
   // frames at or beyond len[s] are not touched by the kernel: hand them back as zeros
-  if (rc == GMR_OK && len && (e = hipMemset(d + o_qo, 0, (o_st - o_qo))) != hipSuccess)
+  if (rc == GMR_OK && len && (e = hipMemsetAsync(d + o_qo, 0, out_bytes, nullptr)) != hipSuccess)
     rc = fail(GMR_ERR_HIP, "memset: %s", hipGetErrorString(e));
   if (rc == GMR_OK)
     rc = gmr_retarget_streams_dev(s, S, T, (double*)(d + o_q0), (double*)(d + o_h), len ? (int32_t*)(d + o_len) : nullptr,
                                   flags, (double*)(d + o_qo), (int32_t*)(d + o_ns), (int32_t*)(d + o_st), nullptr);
-  if (rc == GMR_OK) {
-    if ((e = hipDeviceSynchronize()) != hipSuccess ||
-        (e = hipMemcpy(q_out, d + o_qo, b_qo, hipMemcpyDeviceToHost)) != hipSuccess ||
-        (e = hipMemcpy(nsolve, d + o_ns, b_ns, hipMemcpyDeviceToHost)) != hipSuccess ||
-        (e = hipMemcpy(status, d + o_st, b_st, hipMemcpyDeviceToHost)) != hipSuccess)
+  if (rc == GMR_OK && small) {
+    if ((e = hipMemcpyAsync(s->pin + o_qo, d + o_qo, out_bytes, hipMemcpyDeviceToHost, nullptr)) != hipSuccess ||
+        (e = hipStreamSynchronize(nullptr)) != hipSuccess)
+      rc = fail(GMR_ERR_HIP, "kernel / D2H copy: %s", hipGetErrorString(e));
+    else {
+      memcpy(q_out, s->pin + o_qo, b_qo);
+      memcpy(nsolve, s->pin + o_ns, b_ns);
+      memcpy(status, s->pin + o_st, b_st);
+    }
+  } else if (rc == GMR_OK) {
+    if ((e = hipMemcpyAsync(q_out, d + o_qo, b_qo, hipMemcpyDeviceToHost, nullptr)) != hipSuccess ||
+        (e = hipMemcpyAsync(nsolve, d + o_ns, b_ns, hipMemcpyDeviceToHost, nullptr)) != hipSuccess ||
+        (e = hipMemcpyAsync(status, d + o_st, b_st, hipMemcpyDeviceToHost, nullptr)) != hipSuccess ||
+        (e = hipStreamSynchronize(nullptr)) != hipSuccess)
       rc = fail(GMR_ERR_HIP, "kernel / D2H copy: %s", hipGetErrorString(e));
   }
-  (void)hipFree(d);
   return rc;
 }
 

@@ -26,7 +26,7 @@ __device__ __forceinline__ d4 qmul(d4 a, d4 b) {
 __device__ __forceinline__ d4 qconj(d4 a) { return {a.w, -a.x, -a.y, -a.z}; }
 __device__ __forceinline__ d4 qnormalize(d4 a) {
   double n2 = a.w * a.w + a.x * a.x + a.y * a.y + a.z * a.z;
-  double s = 1.0 / sqrt(n2);
+  double s = rsqrt(n2);
   return {a.w * s, a.x * s, a.y * s, a.z * s};
 }
 // rotate v by unit quaternion q: v + 2 w (u x v) + 2 u x (u x v)

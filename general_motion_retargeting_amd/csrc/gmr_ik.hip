@@ -388,10 +388,18 @@ __device__ __forceinline__ int solve_qp_regs(const IkLayout& L, double* sm, int 
       double l = r[j] * dinv;
       r[j] = l;
       if (lane == j) mydinv = dinv;
+      // trailing update, four columns per group: the four SGPR pairs are read first so that the
+      // VALU-writes-SGPR wait states of one pair are covered by the reads of the next
 #pragma unroll
-      for (int k = j + 1; k < NVP; k++) {
-        double lk = readlane_d(l, k);
-        r[k] = fma(-l, lk, r[k]);
+      for (int k0 = j + 1; k0 < NVP; k0 += 4) {
+        double lk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) lk[u] = (k0 + u < NVP) ? readlane_d(l, k0 + u) : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (k0 + u < NVP) r[k0 + u] = fma(-l, lk[u], r[k0 + u]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (bad) return GMR_STATUS_QP_FAILED;
@@ -535,9 +543,8 @@ __device__ __forceinline__ void preprocess_wave(const IkLayout& L, double* sm, c
 // the kernel
 // ---------------------------------------------------------------------------------------------
 template <int NVP>
-__global__ __launch_bounds__(64) void ik_streams_kernel(const gmr_model_t* __restrict__ model,
-                                                        const gmr_taskset_t* __restrict__ ts,
-                                                        const uint32_t* __restrict__ sched, IkLayout L, int S, int T,
+__global__ __launch_bounds__(64) void ik_streams_kernel(const uint4* __restrict__ image, IkLayout L, IkParams P,
+                                                        int S, int T,
                                                         const double* __restrict__ q0,
                                                         const double* __restrict__ human,
                                                         const int32_t* __restrict__ len, int flags,
@@ -563,53 +570,18 @@ __global__ __launch_bounds__(64) void ik_streams_kernel(const gmr_model_t* __res
   short* limited = si + L.i_limited;
   short* is_foot = si + L.i_is_foot;
 
-  // ---- stage the constants into LDS --------------------------------------------------------
-  const int nb = L.nb, nh = L.nh, nv = L.nv, nq = L.nq, nhum = L.nhum;
-  for (int i = lane; i < nb; i += 64) {
-    for (int a = 0; a < 3; a++) (sm + L.body_pos)[3 * i + a] = model->body_pos[i][a];
-    for (int a = 0; a < 4; a++) (sm + L.body_quat)[4 * i + a] = model->body_quat[i][a];
-    int h = model->body_hinge[i];
-    for (int a = 0; a < 3; a++) (sm + L.axis)[3 * i + a] = h >= 0 ? model->hinge_axis[h][a] : 0.0;
-    int dep = model->depth[i];
-    depth[i] = (short)dep;
-    body_hinge[i] = (short)h;
-    for (int r = 0; r < L.nhop; r++) hop[r * nb + i] = (short)(dep >= (1 << r) ? model->chain[i][dep - (1 << r)] : 0);
+  // ---- stage the constants: one coalesced copy of the host-built LDS image ---------------------
+  const int nv = L.nv, nq = L.nq, nhum = L.nhum;
+  {
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    const int n16 = (L.smem_bytes + 15) >> 4;
+    for (int i = lane; i < n16; i += 64) dst[i] = image[i];
   }
-  for (int i = lane; i < nh; i += 64) {
-    (sm + L.range_lo)[i] = model->range_lo[i];
-    (sm + L.range_hi)[i] = model->range_hi[i];
-    hinge_body[i] = (short)model->hinge_body[i];
-    limited[i] = (short)model->limited[i];
-  }
-  for (int i = lane; i < nhum; i += 64) {
-    (sm + L.scale)[i] = ts->scale[i];
-    for (int a = 0; a < 3; a++) (sm + L.pos_off)[3 * i + a] = ts->pos_off[i][a];
-    for (int a = 0; a < 4; a++) (sm + L.quat_off)[4 * i + a] = ts->quat_off[i][a];
-    is_foot[i] = (short)ts->is_foot[i];
-  }
-  for (int i = lane; i < L.n_word; i += 64) sw[i] = sched[i];
-  for (int st = 0; st < 2; st++) {
-    short* tb = si + L.i_task_body[st];
-    short* th = si + L.i_task_human[st];
-    short* pt = si + L.i_pair_task[st];
-    short* pd = si + L.i_pair_dof[st];
-    short* pi = si + L.i_pair_index[st];
-    for (int k = lane; k < L.K[st]; k += 64) {
-      tb[k] = (short)ts->task_body[st][k];
-      th[k] = (short)ts->task_human[st][k];
-      (sm + L.wpos[st])[k] = ts->w_pos[st][k];
-      (sm + L.wrot[st])[k] = ts->w_rot[st][k];
-    }
-    for (int p = lane; p < L.P[st]; p += 64) {
-      pt[p] = (short)ts->pair_task[st][p];
-      pd[p] = (short)ts->pair_dof[st][p];
-    }
-    for (int i = lane; i < L.K[st] * nv; i += 64) pi[i] = (short)ts->pair_index[st][i / nv][i % nv];
-  }
-  const double damping = ts->damping, lm_damping = ts->lm_damping, tol = ts->tol, limit_gain = ts->limit_gain;
-  const double ground_offset = ts->ground_offset, dt = model->timestep;
-  const int max_iter = ts->max_iter, human_root = ts->human_root;
-  const int use0 = ts->use_stage[0], use1 = ts->use_stage[1];
+  const double damping = P.damping, lm_damping = P.lm_damping, tol = P.tol, limit_gain = P.limit_gain;
+  const double ground_offset = P.ground_offset, dt = P.dt;
+  const int max_iter = P.max_iter, human_root = P.human_root;
+  const int use0 = P.use0, use1 = P.use1;
+  WSYNC();
 
   for (int i = lane; i < nq; i += 64) (sm + L.q)[i] = q0[(size_t)s * nq + i];
   WSYNC();
@@ -693,25 +665,26 @@ __global__ __launch_bounds__(64) void ik_streams_kernel(const gmr_model_t* __res
 
 // host-side launcher used by gmr_abi.hip
 template <int NVP>
-static hipError_t launch_nvp(const gmr_model_t* d_model, const gmr_taskset_t* d_ts, const uint32_t* d_sched,
-                             const gmr::IkLayout* L, int S, int T, const double* d_q0, const double* d_human,
+static hipError_t launch_nvp(const uint4* d_image, const gmr::IkLayout* L, const gmr::IkParams* P, int S, int T,
+                             const double* d_q0, const double* d_human,
                              const int32_t* d_len, int flags, double* d_q_out, int32_t* d_nsolve, int32_t* d_status,
                              hipStream_t stream, unsigned long long* d_prof) {
-  hipLaunchKernelGGL(gmr::ik_streams_kernel<NVP>, dim3(S), dim3(64), L->smem_bytes, stream, d_model, d_ts, d_sched,
-                     *L, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, d_prof);
+  hipLaunchKernelGGL(gmr::ik_streams_kernel<NVP>, dim3(S), dim3(64), L->smem_bytes, stream, d_image, *L, *P, S, T,
+                     d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, d_prof);
   return hipGetLastError();
 }
 
-extern "C" hipError_t gmr_launch_ik_streams(const gmr_model_t* d_model, const gmr_taskset_t* d_ts,
-                                            const uint32_t* d_sched, const gmr::IkLayout* L, int S, int T,
-                                            const double* d_q0, const double* d_human, const int32_t* d_len,
+extern "C" hipError_t gmr_launch_ik_streams(const uint4* d_image, const gmr::IkLayout* L, const gmr::IkParams* P,
+                                            int S, int T, const double* d_q0, const double* d_human,
+                                            const int32_t* d_len,
                                             int flags, double* d_q_out, int32_t* d_nsolve, int32_t* d_status,
                                             hipStream_t stream, unsigned long long* d_prof) {
   if (S <= 0 || T <= 0) return hipSuccess;
   switch (L->nvp) {
-    case 28: return launch_nvp<28>(d_model, d_ts, d_sched, L, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream, d_prof);
-    case 32: return launch_nvp<32>(d_model, d_ts, d_sched, L, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream, d_prof);
-    case 36: return launch_nvp<36>(d_model, d_ts, d_sched, L, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream, d_prof);
+    case 28: return launch_nvp<28>(d_image, L, P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream, d_prof);
+    case 32: return launch_nvp<32>(d_image, L, P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream, d_prof);
+    case 36: return launch_nvp<36>(d_image, L, P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream, d_prof);
+    case 48: return launch_nvp<48>(d_image, L, P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream, d_prof);
     default: return hipErrorInvalidValue;
   }
 }
@@ -722,6 +695,7 @@ extern "C" hipError_t gmr_ik_set_max_smem(int nvp, int bytes) {
     case 28: f = reinterpret_cast<const void*>(gmr::ik_streams_kernel<28>); break;
     case 32: f = reinterpret_cast<const void*>(gmr::ik_streams_kernel<32>); break;
     case 36: f = reinterpret_cast<const void*>(gmr::ik_streams_kernel<36>); break;
+    case 48: f = reinterpret_cast<const void*>(gmr::ik_streams_kernel<48>); break;
     default: return hipErrorInvalidValue;
   }
   return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "../../include/gmr_types.h"
@@ -36,6 +37,7 @@ inline int ik_padded_nv(int nv) {
   if (nv <= 28) return 28;
   if (nv <= 32) return 32;
   if (nv <= 36) return 36;
+  if (nv <= 48) return 48;   // generic upper size (GMR_MAX_DOF = 46); none of the shipped robots needs it
   return -1;
 }
 
@@ -143,6 +145,71 @@ inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, co
   L.n_short = i;
   L.smem_bytes = L.n_double * 8 + L.n_word * 4 + ((L.n_short * 2 + 15) / 16) * 16;
   return L;
+}
+
+// scalar parameters of a solve, passed by value to the kernel
+struct IkParams {
+  double damping, lm_damping, tol, limit_gain, ground_offset, dt;
+  int max_iter, human_root, use0, use1;
+};
+
+inline IkParams make_ik_params(const gmr_model_t& m, const gmr_taskset_t& ts) {
+  IkParams p;
+  p.damping = ts.damping; p.lm_damping = ts.lm_damping; p.tol = ts.tol; p.limit_gain = ts.limit_gain;
+  p.ground_offset = ts.ground_offset; p.dt = m.timestep;
+  p.max_iter = ts.max_iter; p.human_root = ts.human_root; p.use0 = ts.use_stage[0]; p.use1 = ts.use_stage[1];
+  return p;
+}
+
+// Host-built image of one stream's LDS: the constant regions filled, the state regions zero.  The
+// kernel prologue is then one coalesced global -> LDS copy instead of dozens of scattered loads
+// (matters for the per-frame entry point, where the prologue is paid on every call).
+inline std::vector<char> make_ik_image(const gmr_model_t& m, const gmr_taskset_t& ts, const IkSchedule& sch,
+                                       const IkLayout& L) {
+  std::vector<char> img(((size_t)L.smem_bytes + 15) / 16 * 16, 0);
+  double* sm = reinterpret_cast<double*>(img.data());
+  uint32_t* sw = reinterpret_cast<uint32_t*>(sm + L.n_double);
+  short* si = reinterpret_cast<short*>(sw + L.n_word);
+  const int nb = L.nb, nv = L.nv;
+  for (int i = 0; i < nb; i++) {
+    for (int a = 0; a < 3; a++) sm[L.body_pos + 3 * i + a] = m.body_pos[i][a];
+    for (int a = 0; a < 4; a++) sm[L.body_quat + 4 * i + a] = m.body_quat[i][a];
+    int hh = m.body_hinge[i];
+    for (int a = 0; a < 3; a++) sm[L.axis + 3 * i + a] = hh >= 0 ? m.hinge_axis[hh][a] : 0.0;
+    int dep = m.depth[i];
+    si[L.i_depth + i] = (short)dep;
+    si[L.i_body_hinge + i] = (short)hh;
+    for (int r = 0; r < L.nhop; r++)
+      si[L.i_hop + r * nb + i] = (short)(dep >= (1 << r) ? m.chain[i][dep - (1 << r)] : 0);
+  }
+  for (int i = 0; i < L.nh; i++) {
+    sm[L.range_lo + i] = m.range_lo[i];
+    sm[L.range_hi + i] = m.range_hi[i];
+    si[L.i_hinge_body + i] = (short)m.hinge_body[i];
+    si[L.i_limited + i] = (short)m.limited[i];
+  }
+  for (int i = 0; i < L.nhum; i++) {
+    sm[L.scale + i] = ts.scale[i];
+    for (int a = 0; a < 3; a++) sm[L.pos_off + 3 * i + a] = ts.pos_off[i][a];
+    for (int a = 0; a < 4; a++) sm[L.quat_off + 4 * i + a] = ts.quat_off[i][a];
+    si[L.i_is_foot + i] = (short)ts.is_foot[i];
+  }
+  for (int s = 0; s < 2; s++) {
+    for (size_t i = 0; i < sch.items[s].size(); i++) sw[L.w_items[s] + i] = sch.items[s][i];
+    for (int l = 0; l < 65; l++) sw[L.w_istart[s] + l] = (uint32_t)sch.istart[s][l];
+    for (int k = 0; k < L.K[s]; k++) {
+      si[L.i_task_body[s] + k] = (short)ts.task_body[s][k];
+      si[L.i_task_human[s] + k] = (short)ts.task_human[s][k];
+      sm[L.wpos[s] + k] = ts.w_pos[s][k];
+      sm[L.wrot[s] + k] = ts.w_rot[s][k];
+      for (int d = 0; d < nv; d++) si[L.i_pair_index[s] + k * nv + d] = (short)ts.pair_index[s][k][d];
+    }
+    for (int p = 0; p < L.P[s]; p++) {
+      si[L.i_pair_task[s] + p] = (short)ts.pair_task[s][p];
+      si[L.i_pair_dof[s] + p] = (short)ts.pair_dof[s][p];
+    }
+  }
+  return img;
 }
 
 }  // namespace gmr

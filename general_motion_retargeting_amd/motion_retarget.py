@@ -116,7 +116,8 @@ class GeneralMotionRetargeting:
         self.damping = damping
         self.pos_offsets1 = {k: v.copy() for k, v in tt.pos_offsets1.items()}
         self.rot_offsets1 = {k: v.copy() for k, v in tt.rot_offsets1.items()}   # wxyz, normalised
-        self.scaled_human_data = None
+        self._scaled_src = None
+        self._scaled_cache = None
 
         self._human_names: List[str] = tt.human_names
         self._model_blob = pack_model(self.model)
@@ -181,11 +182,26 @@ class GeneralMotionRetargeting:
     def update_targets(self, human_data, offset_to_ground=False):
         human_data = self.to_numpy(human_data)
         self._raw_frame = self.pack_frame(human_data)
-        hd = self.scale_human_data(human_data, self.human_root_name, self.human_scale_table)
-        hd = self.offset_human_data(hd, self.pos_offsets1, self.rot_offsets1)
-        if offset_to_ground:
-            hd = self.offset_human_data_to_ground(hd)
-        self.scaled_human_data = hd
+        # the reference computes scaled_human_data eagerly (:118-124); only viewers read it, so it is
+        # derived on first access here (the IK consumes the raw packed frame and preprocesses on device)
+        self._scaled_src = (human_data, bool(offset_to_ground))
+        self._scaled_cache = None
+
+    @property
+    def scaled_human_data(self):
+        if self._scaled_cache is None and self._scaled_src is not None:
+            human_data, ground = self._scaled_src
+            hd = self.scale_human_data(human_data, self.human_root_name, self.human_scale_table)
+            hd = self.offset_human_data(hd, self.pos_offsets1, self.rot_offsets1)
+            if ground:
+                hd = self.offset_human_data_to_ground(hd)
+            self._scaled_cache = hd
+        return self._scaled_cache
+
+    @scaled_human_data.setter
+    def scaled_human_data(self, value):
+        self._scaled_cache = value
+        self._scaled_src = None
 
     def retarget(self, human_data, offset_to_ground=False):
         """One frame (reference :139-185): warm-started from the previous call, returns qpos f64[nq]."""

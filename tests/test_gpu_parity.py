@@ -266,3 +266,59 @@ def test_full_size_config2_properties(hip, oracle, g1):
     perm = np.random.default_rng(0).permutation(100)[:17]
     q_p, _, _ = sol.retarget_streams(q0[perm], human[perm])
     assert np.array_equal(q_p, q_h[perm])
+
+
+def test_mixed_robot_batch_concurrent_streams(hip, oracle):
+    """configs[3] shape: several robots in one call, one kernel per robot model on its own HIP stream."""
+    from general_motion_retargeting_amd import dataset, synth
+    specs = [("smplx", "unitree_g1", None), ("smplx", "booster_t1", 1.7), ("smplx", "hightorque_hi", None),
+             ("bvh", "engineai_pm01", None), ("smplx", "kuavo_s45", 1.6), ("smplx", "stanford_toddy", None),
+             ("smplx", "fourier_n1", None)]
+    groups, setups = [], []
+    for i, (src, robot, h) in enumerate(specs):
+        su = get_setup(src, robot, h)
+        human, q0 = synth.make_streams(su.model, su.tt, 3, 8, seed=50 + i)
+        groups.append({"src_human": src, "tgt_robot": robot, "actual_human_height": h, "human": human})
+        setups.append((su, human, q0))
+    res = dataset.retarget_mixed(groups)
+    for (su, human, q0), (q_h, ns_h, st_h) in zip(setups, res):
+        q_o, ns_o, _ = oracle.retarget_streams(su.mb, su.ts, q0, human)
+        assert (st_h == 0).all() and np.array_equal(ns_h, ns_o)
+        joint, pos, rot = _compare(q_h, q_o)
+        assert joint <= TOL_RAD and pos <= TOL_POS and rot <= TOL_RAD, (su.robot, joint, pos, rot)
+
+
+def test_generic_large_robot_nvp48(hip, oracle, tmp_path):
+    """A synthetic 40-hinge chain robot (nv = 46 = GMR_MAX_DOF) exercises the NVP=48 instantiation."""
+    import json
+    from general_motion_retargeting_amd import synth
+    from general_motion_retargeting_amd.ik_config import build_task_tables, pack_model, pack_taskset
+    from general_motion_retargeting_amd.mjcf import compile_mjcf
+    axes = ["1 0 0", "0 1 0", "0 0 1"]
+    def chain(prefix, n, pos):
+        s, e = "", ""
+        for i in range(n):
+            s += f'<body name="{prefix}{i}" pos="{pos if i == 0 else "0 0 -0.08"}"><joint name="{prefix}j{i}" axis="{axes[i % 3]}" range="-1.2 1.2"/>'
+            e += "</body>"
+        return s + e
+    xml = ('<mujoco model="many"><compiler angle="radian"/><worldbody><body name="base" pos="0 0 1"><freejoint/>'
+           + chain("a", 10, "0 0.1 0") + chain("b", 10, "0 -0.1 0") + chain("c", 10, "0.1 0 0.2") + chain("d", 10, "-0.1 0 0.2")
+           + "</body></worldbody></mujoco>")
+    p = tmp_path / "many.xml"
+    p.write_text(xml)
+    model = compile_mjcf(str(p))
+    assert model.nv == 46
+    names = ["root", "ha", "hb", "hc", "hd", "ma", "mb"]
+    frames = ["base", "a9", "b9", "c9", "d9", "a4", "b4"]
+    tbl = {f: [h, 50, 10, [0, 0, 0], [1, 0, 0, 0]] for f, h in zip(frames, names)}
+    cfg = {"robot_root_name": "base", "human_root_name": "root", "ground_height": 0.0, "human_height_assumption": 1.8,
+           "use_ik_match_table1": True, "use_ik_match_table2": True, "human_scale_table": {n: 1.0 for n in names},
+           "ik_match_table1": tbl, "ik_match_table2": json.loads(json.dumps(tbl))}
+    tt = build_task_tables(cfg)
+    mb, ts = pack_model(model), pack_taskset(model, tt)
+    human, q0 = synth.make_streams(model, tt, 3, 6, seed=8)
+    q_o, ns_o, st_o = oracle.retarget_streams(mb, ts, q0, human)
+    q_h, ns_h, st_h = hip.Solver(mb, ts).retarget_streams(q0, human)
+    assert (st_h == 0).all() and (st_o == 0).all() and np.array_equal(ns_h, ns_o)
+    joint, pos, rot = _compare(q_h, q_o)
+    assert joint <= 1e-8 and pos <= 1e-8 and rot <= 1e-8, (joint, pos, rot)
