@@ -66,11 +66,16 @@ def main():
 
     dist = None
     torch = None
+    backend = os.environ.get("GMR_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 path on one GPU
     if world > 1:
         import torch  # plumbing only: rendezvous, RCCL broadcast, barrier
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    comm_dev = "cuda" if backend == "nccl" else "cpu"
 
     # ---- rank 0 compiles the robot + task set; ONE broadcast ships it to the peers ----------
     nbytes = MODEL_DTYPE.itemsize + TASKSET_DTYPE.itemsize
@@ -82,7 +87,7 @@ def main():
     else:
         blob = np.zeros(nbytes, dtype=np.uint8)
     if world > 1:
-        t = torch.from_numpy(blob).cuda()
+        t = torch.from_numpy(blob).to(comm_dev)
         dist.broadcast(t, src=0)          # RCCL over xGMI, ~24 KB, once
         blob = t.cpu().numpy()
     mb = blob[: MODEL_DTYPE.itemsize].view(MODEL_DTYPE).copy()
@@ -105,9 +110,11 @@ def main():
     def sync_all():
         _lib.check(L.gmr_stream_sync(None))
         if world > 1:
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
 
     def step(ev0=None, ev1=None):
         if ev0 is not None:
@@ -128,7 +135,7 @@ def main():
     kern_ms = [a.elapsed_ms(b) for a, b in evs]
 
     if world > 1:
-        tt_ = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt_ = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
         elapsed = float(tt_.item())
 

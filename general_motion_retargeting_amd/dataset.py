@@ -107,3 +107,15 @@ def retarget_mixed(groups: Sequence[Dict], offset_to_ground: bool = False):
         out.append((d_qo.to_host((S, T, sol.nq), np.float64), d_ns.to_host((S, T, 2), np.int32),
                     d_st.to_host((S,), np.int32)))
     return out
+
+
+def retarget_bvh_files(bvh_files: Sequence[str], tgt_robot: str, fps: float = 30.0, height_adjust: bool = False,
+                       root_origin_offset: bool = False) -> List[Dict]:
+    """``scripts/bvh_to_robot_dataset.py:60-152`` for a list of files: every BVH clip becomes one
+    stream of ONE launch (LAFAN1: 77 ragged clips).  Both adjustments default to off like that script
+    (``HEIGHT_ADJUST = False``, :128); the loader's hard-coded height 1.75 is used (lafan1.py:39)."""
+    from .utils.lafan1 import load_lafan1_packed
+    gmr = GeneralMotionRetargeting("bvh", tgt_robot, actual_human_height=1.75)
+    clips = [load_lafan1_packed(f, gmr.human_body_names)[0] for f in bvh_files]
+    return retarget_clips("bvh", tgt_robot, clips, [fps] * len(clips), actual_human_height=1.75,
+                          height_adjust=height_adjust, root_origin_offset=root_origin_offset)

@@ -12,6 +12,10 @@ is importable in the build container:
   CPU torch for the 7 robots it can parse: parsed tree arrays and ``forward_kinematics`` outputs
   for seeded random inputs.  This pins rows H8-H9.
 
+* G-BVH  -- the reference's LAFAN1 loader (``utils/lafan1.py`` + ``utils/lafan_vendor``, NumPy/SciPy
+  only) on ``tests/golden/synthetic.bvh`` (a 22-joint, 12-frame BVH authored by this repository).
+  This pins the "next" row N2.
+
 Nothing here pins rows H4-H7 (the mink/MuJoCo/DAQP numerics): "parity unpinned", see DESIGN.md.
 
 Only numbers and names are stored (``np.savez_compressed``; loadable with allow_pickle=False).
@@ -180,6 +184,23 @@ def make_fk():
     print("g_fk.npz:", len(out), "arrays")
 
 
+
+
+def make_bvh():
+    """G-BVH: the reference's LAFAN1 loader (utils/lafan1.py + lafan_vendor, NumPy/SciPy only) on the
+    small synthetic BVH authored by this repository (tests/golden/synthetic.bvh)."""
+    pkg = "general_motion_retargeting"
+    if pkg not in sys.modules:
+        p = types.ModuleType(pkg); p.__path__ = [str(REF / pkg)]; sys.modules[pkg] = p
+    lafan1 = importlib.import_module(f"{pkg}.utils.lafan1")
+    frames, height = lafan1.load_lafan1_file(str(OUT / "synthetic.bvh"))
+    names = list(frames[0].keys())
+    arr = np.array([[np.concatenate([f[n][0], f[n][1]]) for n in names] for f in frames])
+    np.savez_compressed(OUT / "g_bvh.npz", names=np.array(names), poses=arr, height=np.array(height))
+    print("g_bvh.npz:", arr.shape)
+
+
 if __name__ == "__main__":
     make_pre()
     make_fk()
+    make_bvh()
