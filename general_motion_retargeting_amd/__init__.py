@@ -9,6 +9,7 @@ from .params import IK_CONFIG_ROOT, ASSET_ROOT, ROBOT_XML_DICT, IK_CONFIG_DICT, 
 from .motion_retarget import GeneralMotionRetargeting, TargetNotSet
 from .data_loader import load_robot_motion, save_robot_motion
 from .kinematics_model import KinematicsModel
+from . import dataset, sharding, synth
 
 
 class RobotMotionViewer:  # pragma: no cover - out of scope (GUI), kept so imports do not break
