@@ -43,6 +43,7 @@ _SIGS = {
     "gmr_solver_create": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "gmr_solver_destroy": (C.c_int, [C.c_void_p]),
     "gmr_solver_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gmr_solver_set_waves": (C.c_int, [C.c_void_p, C.c_int]),
     "gmr_retarget_lds_bytes": (C.c_int, [C.c_void_p]),
     "gmr_retarget_streams_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -185,6 +186,10 @@ class Solver:
         self.nq = int(model_blob["nq"][0])
         self.nv = int(model_blob["nv"][0])
         self.nhuman = int(taskset_blob["nhuman"][0])
+
+    def set_waves(self, waves_per_stream: int) -> None:
+        """0 = automatic, 1 = one wavefront per stream, 4 = main + 3 helper wavefronts per stream."""
+        check(lib().gmr_solver_set_waves(self.handle, int(waves_per_stream)))
 
     @property
     def lds_bytes(self) -> int:

@@ -21,10 +21,14 @@ static_assert(offsetof(gmr_taskset_t, damping) % 8 == 0, "double block of gmr_ta
 extern "C" hipError_t gmr_launch_ik_streams(const uint4*, const gmr::IkLayout*, const gmr::IkParams*, int, int,
                                             const double*, const double*, const int32_t*, int, double*, int32_t*,
                                             int32_t*, hipStream_t, unsigned long long*);
-extern "C" hipError_t gmr_ik_set_max_smem(int nvp, int bytes);
+extern "C" hipError_t gmr_ik_set_max_smem(int nvp, int nw, int bytes);
 extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree*, int, int, int, const float*, const float*, const float*,
                                           float*, float*, float*, float*, hipStream_t);
 extern "C" int gmr_fk_blocks(int nbody, int B);
+
+// up to this many streams a launch uses the 4-wave (main + 3 helpers) shape: 768 streams x 4 waves fill
+// the 3 LDS-limited workgroup slots of every CU
+#define GMR_HELPER_MAX_STREAMS 768
 
 namespace {
 thread_local char g_err[512] = "";
@@ -45,7 +49,10 @@ int fail(int code, const char* fmt, ...) {
 struct gmr_solver {
   gmr_model_t model;
   gmr_taskset_t ts;
-  gmr::IkLayout layout;
+  gmr::IkLayout layout;          // one wave per stream (many streams)
+  gmr::IkLayout layout4;         // main wave + 3 helpers per stream (few streams: latency shape)
+  uint4* d_image4 = nullptr;
+  int force_waves = 0;           // 0 = choose by stream count, 1 or 4 = forced (gmr_solver_set_waves)
   gmr::IkParams params;
   uint4* d_image = nullptr;      // host-built LDS image of the constants (gmr_ik_layout.h)
   char* ws = nullptr;            // grow-only device workspace of the host-buffer entry point
@@ -192,16 +199,23 @@ int gmr_solver_create(const gmr_model_t* model, const gmr_taskset_t* taskset, gm
   s->model = *model;
   s->ts = *taskset;
   if (gmr::ik_padded_nv(s->model.nv) < 0) { delete s; return fail(GMR_ERR_ARG, "nv = %d > 48 is not supported", s->model.nv); }
-  gmr::IkSchedule sch = gmr::make_ik_schedule(s->model, s->ts);
-  s->layout = gmr::make_ik_layout(s->model, s->ts, sch);
-  if (s->layout.smem_bytes > 160 * 1024) { delete s; return fail(GMR_ERR_ARG, "robot too large for LDS"); }
   s->params = gmr::make_ik_params(s->model, s->ts);
-  std::vector<char> img = gmr::make_ik_image(s->model, s->ts, sch, s->layout);
-  hipError_t e;
-  if ((e = hipMalloc((void**)&s->d_image, img.size())) != hipSuccess ||
-      (e = hipMemcpy(s->d_image, img.data(), img.size(), hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = gmr_ik_set_max_smem(s->layout.nvp, s->layout.smem_bytes)) != hipSuccess) {
+  hipError_t e = hipSuccess;
+  for (int v = 0; v < 2 && e == hipSuccess; v++) {
+    const int nw = v == 0 ? 1 : 4;
+    gmr::IkSchedule sch = gmr::make_ik_schedule(s->model, s->ts, v == 0 ? 64 : 64 * (nw - 1));
+    gmr::IkLayout& lay = v == 0 ? s->layout : s->layout4;
+    lay = gmr::make_ik_layout(s->model, s->ts, sch, nw);
+    if (lay.smem_bytes > 160 * 1024 - 1024) { delete s; return fail(GMR_ERR_ARG, "robot too large for LDS"); }
+    std::vector<char> img = gmr::make_ik_image(s->model, s->ts, sch, lay);
+    uint4** dst = v == 0 ? &s->d_image : &s->d_image4;
+    if ((e = hipMalloc((void**)dst, img.size())) != hipSuccess) break;
+    if ((e = hipMemcpy(*dst, img.data(), img.size(), hipMemcpyHostToDevice)) != hipSuccess) break;
+    e = gmr_ik_set_max_smem(lay.nvp, nw, lay.smem_bytes);
+  }
+  if (e != hipSuccess) {
     if (s->d_image) (void)hipFree(s->d_image);
+    if (s->d_image4) (void)hipFree(s->d_image4);
     delete s;
     return fail(GMR_ERR_HIP, "gmr_solver_create: %s", hipGetErrorString(e));
   }
@@ -212,6 +226,7 @@ int gmr_solver_create(const gmr_model_t* model, const gmr_taskset_t* taskset, gm
 int gmr_solver_destroy(gmr_solver_t* s) {
   if (!s) return GMR_OK;
   (void)hipFree(s->d_image);
+  (void)hipFree(s->d_image4);
   if (s->ws) (void)hipFree(s->ws);
   if (s->pin) (void)hipHostFree(s->pin);
   delete s;
@@ -226,7 +241,15 @@ int gmr_solver_dims(const gmr_solver_t* s, int* nq, int* nv, int* nhuman) {
   return GMR_OK;
 }
 
-int gmr_retarget_lds_bytes(const gmr_solver_t* s) { return s ? s->layout.smem_bytes : 0; }
+int gmr_solver_set_waves(gmr_solver_t* s, int waves_per_stream) {
+  if (!s) return fail(GMR_ERR_ARG, "null solver");
+  if (waves_per_stream != 0 && waves_per_stream != 1 && waves_per_stream != 4)
+    return fail(GMR_ERR_ARG, "waves_per_stream must be 0 (auto), 1 or 4");
+  s->force_waves = waves_per_stream;
+  return GMR_OK;
+}
+
+int gmr_retarget_lds_bytes(const gmr_solver_t* s) { return s ? s->layout4.smem_bytes : 0; }
 
 int gmr_retarget_streams_dev(gmr_solver_t* s, int S, int T, const double* d_q0, const double* d_human,
                              const int32_t* d_len, int flags, double* d_q_out, int32_t* d_nsolve,
@@ -235,8 +258,11 @@ int gmr_retarget_streams_dev(gmr_solver_t* s, int S, int T, const double* d_q0, 
   if (S < 0 || T < 0) return fail(GMR_ERR_ARG, "negative S/T");
   if (S == 0 || T == 0) return GMR_OK;
   if (!d_q0 || !d_human || !d_q_out || !d_nsolve || !d_status) return fail(GMR_ERR_ARG, "null device buffer");
-  HIP_TRY(gmr_launch_ik_streams(s->d_image, &s->layout, &s->params, S, T, d_q0, d_human, d_len, flags, d_q_out,
-                                d_nsolve, d_status, (hipStream_t)stream, nullptr));
+  // few streams: 4 waves per stream (helpers share the wide assembly phases, shorter per-frame
+  // latency); many streams: 1 wave per stream (more streams resident, more frames per second)
+  const bool wide = s->force_waves ? s->force_waves == 4 : S <= GMR_HELPER_MAX_STREAMS;
+  HIP_TRY(gmr_launch_ik_streams(wide ? s->d_image4 : s->d_image, wide ? &s->layout4 : &s->layout, &s->params, S, T,
+                                d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, (hipStream_t)stream, nullptr));
   return GMR_OK;
 }
 
@@ -244,8 +270,9 @@ int gmr_retarget_streams_dev(gmr_solver_t* s, int S, int T, const double* d_q0, 
 // diagnostic builds only (tools/phase_profile.py): per-stream phase cycle counters
 int gmr_retarget_streams_prof(gmr_solver_t* s, int S, int T, const double* d_q0, const double* d_human, int flags,
                               double* d_q_out, int32_t* d_nsolve, int32_t* d_status, unsigned long long* d_prof) {
-  HIP_TRY(gmr_launch_ik_streams(s->d_image, &s->layout, &s->params, S, T, d_q0, d_human, nullptr, flags, d_q_out,
-                                d_nsolve, d_status, nullptr, d_prof));
+  const bool wide = s->force_waves ? s->force_waves == 4 : S <= GMR_HELPER_MAX_STREAMS;
+  HIP_TRY(gmr_launch_ik_streams(wide ? s->d_image4 : s->d_image, wide ? &s->layout4 : &s->layout, &s->params, S, T,
+                                d_q0, d_human, nullptr, flags, d_q_out, d_nsolve, d_status, nullptr, d_prof));
   return GMR_OK;
 }
 #endif

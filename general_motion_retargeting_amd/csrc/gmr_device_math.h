@@ -70,6 +70,20 @@ __device__ __forceinline__ double vinv_coef(double t2) {
   return (1.0 - h * c / s) / t2;
 }
 
+// same coefficient, also handing back sin t and cos t (t = |w|) for the Q coefficients of Jl^-1;
+// below the series switch they are not needed (set to 0 / 1)
+__device__ __forceinline__ double vinv_coef_sc(double t2, double& sin_t, double& cos_t) {
+  if (t2 < 1e-2) {
+    sin_t = 0.0; cos_t = 1.0;
+    return 1.0 / 12.0 + t2 * (1.0 / 720.0 + t2 * (1.0 / 30240.0 + t2 * (1.0 / 1209600.0 + t2 / 47900160.0)));
+  }
+  double t = sqrt(t2), h = 0.5 * t, s, c;
+  sincos(h, &s, &c);
+  sin_t = 2.0 * s * c;
+  cos_t = 1.0 - 2.0 * s * s;
+  return (1.0 - h * c / s) / t2;
+}
+
 // 3x3 row-major helpers
 struct m3 { double a[9]; };
 __device__ __forceinline__ m3 skew(d3 w) {
@@ -93,13 +107,14 @@ __device__ __forceinline__ d3 mvec(const m3& A, d3 v) {
           A.a[6] * v.x + A.a[7] * v.y + A.a[8] * v.z};
 }
 
-// e = log(T_wb^-1 T_wt) = [V^-1(w) p_bt ; w]
-__device__ __forceinline__ void se3_log_rel(d3 pb, d4 qb, d3 pt, d4 qt, double e[6]) {
+// e = log(T_wb^-1 T_wt) = [V^-1(w) p_bt ; w]; aux = {a, sin|w|, cos|w|} is reused by se3_jlinv_aux
+__device__ __forceinline__ void se3_log_rel(d3 pb, d4 qb, d3 pt, d4 qt, double e[6], double aux[3]) {
   d4 qbt = qmul(qconj(qb), qt);
   d3 pbt = qrot_inv(qb, pt - pb);
   d3 w = so3_log(qbt);
   double t2 = dot(w, w);
-  double a = vinv_coef(t2);
+  double a = vinv_coef_sc(t2, aux[1], aux[2]);
+  aux[0] = a;
   // V^-1 p = p - 0.5 w x p + a w x (w x p)
   d3 wp = cross(w, pbt);
   d3 wwp = cross(w, wp);
@@ -144,6 +159,54 @@ __device__ __forceinline__ void se3_jlinv(const double e[6], m3& A, m3& B) {
   m3 AQA = mmul(mmul(A, Q), A);
 #pragma unroll
   for (int i = 0; i < 9; i++) B.a[i] = -AQA.a[i];
+}
+
+// The same Jl^-1(e) with the skew products of Q collapsed by [a]x[b]x = b a^T - (a.b) I
+// (s = w.rho, n = w x rho, m = w x n):
+//   Q = 1/2 [rho]x + c1 (rho w^T + w rho^T) - 2 c1 s I - (c1 + c2) s [w]x - c2 [m]x - 2 c4 s (w w^T - t^2 I)
+//   A = (1 - a t^2) I - 1/2 [w]x + a w w^T
+// two 3x3 products instead of nine; aux = {a, sin t, cos t} from se3_log_rel.
+__device__ __forceinline__ void se3_jlinv_aux(const double e[6], const double aux[3], m3& A, m3& B) {
+  d3 rho = {e[0], e[1], e[2]}, w = {e[3], e[4], e[5]};
+  double t2 = dot(w, w);
+#pragma unroll
+  for (int i = 0; i < 9; i++) { A.a[i] = 0.0; B.a[i] = 0.0; }
+  A.a[0] = A.a[4] = A.a[8] = 1.0;
+  if (t2 < 1e-10) return;
+  const double a = aux[0];
+  double c1, c2, c3;
+  if (t2 < 1e-2) {
+    c1 = 1.0 / 6.0 - t2 / 120.0 + t2 * t2 / 5040.0 - t2 * t2 * t2 / 362880.0;
+    c2 = -1.0 / 24.0 + t2 / 720.0 - t2 * t2 / 40320.0 + t2 * t2 * t2 / 3628800.0;
+    c3 = -1.0 / 120.0 + t2 / 5040.0 - t2 * t2 / 362880.0 + t2 * t2 * t2 / 39916800.0;
+  } else {
+    double t = sqrt(t2), sn = aux[1], cs = aux[2];
+    double it2 = 1.0 / t2, it = 1.0 / t;
+    c1 = (t - sn) * it2 * it;
+    c2 = (1.0 - 0.5 * t2 - cs) * it2 * it2;
+    c3 = (t - sn - t2 * t / 6.0) * it2 * it2 * it;
+  }
+  const double c4 = -0.5 * (c2 - 3.0 * c3);
+  const double s = dot(w, rho);
+  d3 n = cross(w, rho), m = cross(w, n);
+  const double wv[3] = {w.x, w.y, w.z}, rv[3] = {rho.x, rho.y, rho.z};
+  // skew part of Q: 1/2 rho - (c1 + c2) s w - c2 m
+  const double k1 = (c1 + c2) * s;
+  d3 sq = {0.5 * rho.x - k1 * w.x - c2 * m.x, 0.5 * rho.y - k1 * w.y - c2 * m.y, 0.5 * rho.z - k1 * w.z - c2 * m.z};
+  m3 Q = skew(sq);
+  const double dq = -2.0 * c1 * s + 2.0 * c4 * s * t2, kw = -2.0 * c4 * s;
+  m3 Am = skew(d3{-0.5 * w.x, -0.5 * w.y, -0.5 * w.z});
+  const double da = 1.0 - a * t2;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      Q.a[3 * i + j] += c1 * (rv[i] * wv[j] + wv[i] * rv[j]) + kw * wv[i] * wv[j] + (i == j ? dq : 0.0);
+      Am.a[3 * i + j] += a * wv[i] * wv[j] + (i == j ? da : 0.0);
+    }
+  m3 AQA = mmul(mmul(Am, Q), Am);
+#pragma unroll
+  for (int i = 0; i < 9; i++) { A.a[i] = Am.a[i]; B.a[i] = -AQA.a[i]; }
 }
 
 // wave64 butterfly reductions (deterministic, every lane gets the result)

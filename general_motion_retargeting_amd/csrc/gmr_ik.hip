@@ -41,7 +41,18 @@
 
 namespace gmr {
 
-#define WSYNC() __syncthreads()
+// Synchronisation inside ONE wave's phases.  NW == 1: the block is the wave, __syncthreads() is the
+// cheapest full fence.  NW > 1 (helper waves present): the main wave must not touch the workgroup
+// barrier outside the helped phases; LDS operations of one wave execute in order, so a workgroup-scope
+// fence (s_waitcnt + compiler ordering) is all that is needed between its own phases.
+template <int NW>
+__device__ __forceinline__ void wsync() {
+  if (NW == 1) __syncthreads();
+  else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+}
+#define WSYNC() wsync<NW>()
+
+enum { CMD_BUILD = 1, CMD_EXIT = 2 };
 
 // Diagnostic phase timer (GMR_IK_PROFILE builds only; never in the shipped kernel): s_memtime
 // stamps accumulated per phase, written to a buffer no other code reads.
@@ -80,6 +91,7 @@ __device__ __forceinline__ double dot6(const double* a, const double* b) {
 // FK: mj_kinematics semantics (App. A.3), evaluated by pointer jumping.  lane b < nb.
 // Result: (pos, quat) per body at sm[L.xa + 7 b], world hinge axes at sm[L.xaxis + 3 b].
 // ---------------------------------------------------------------------------------------------
+template <int NW>
 __device__ __forceinline__ void fk_wave(const IkLayout& L, double* sm, const short* hop, const short* depth,
                                         const short* body_hinge, int lane, Prof& pr) {
   PROF_BEGIN(pr);
@@ -145,6 +157,7 @@ __device__ __forceinline__ void fk_wave(const IkLayout& L, double* sm, const sho
 // residuals of the stage's tasks (mink FrameTask.compute_error) and their unweighted norm
 // (motion_retarget.py:188-200).  lane k < K.  Returns E in every lane.
 // ---------------------------------------------------------------------------------------------
+template <int NW>
 __device__ __forceinline__ double errors_wave(const IkLayout& L, double* sm, const short* task_body,
                                               const short* task_human, int K, int lane, Prof& pr) {
   PROF_BEGIN(pr);
@@ -153,12 +166,14 @@ __device__ __forceinline__ double errors_wave(const IkLayout& L, double* sm, con
     int b = task_body[lane], h = task_human[lane];
     const double* x = sm + L.xa + 7 * b;
     const double* tg = sm + L.tgt + 7 * h;
-    double e[6];
+    double e[6], aux[3];
     se3_log_rel(d3{x[0], x[1], x[2]}, d4{x[3], x[4], x[5], x[6]}, d3{tg[0], tg[1], tg[2]},
-                d4{tg[3], tg[4], tg[5], tg[6]}, e);
+                d4{tg[3], tg[4], tg[5], tg[6]}, e, aux);
     double* eo = sm + L.e + 6 * lane;
 #pragma unroll
     for (int r = 0; r < 6; r++) { eo[r] = e[r]; ss += e[r] * e[r]; }
+    double* ao = sm + L.eaux + 3 * lane;     // a, sin|w|, cos|w|: reused by the Jl^-1 phase
+    ao[0] = aux[0]; ao[1] = aux[1]; ao[2] = aux[2];
   }
   ss = wave_sum(ss);
   WSYNC();
@@ -167,27 +182,32 @@ __device__ __forceinline__ double errors_wave(const IkLayout& L, double* sm, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// QP assembly (mink compute_qp_objective + ConfigurationLimit; App. A.4-A.6)
+// QP assembly (mink compute_qp_objective + ConfigurationLimit; App. A.4-A.6), in four phases so
+// that helper waves can share the two wide ones (Jacobian columns, H entries)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void build_qp_wave(const IkLayout& L, double* sm, int stage, const short* task_body,
-                                              const short* pair_task, const short* pair_dof,
-                                              const short* pair_index, const short* hinge_body,
-                                              const short* limited, const uint32_t* items, const int* istart,
-                                              double damping, double lm_damping, double limit_gain, int lane,
-                                              Prof& pr) {
+struct StageTabs {
+  const short* task_body; const short* task_human; const short* pair_task; const short* pair_dof;
+  const short* pair_index; const uint32_t* items; const int* istart;
+};
+
+// (a) lane = task: M_k = -Jl^-1(e_k) (blocks -A, -B), weighted residual; returns the LM term mu
+template <int NW>
+__device__ __forceinline__ double jlog_phase(const IkLayout& L, double* sm, int stage, double lm_damping, int lane,
+                                             Prof& pr) {
   PROF_BEGIN(pr);
-  const int K = L.K[stage], P = L.P[stage], nv = L.nv, ldh = L.ldh;
+  const int K = L.K[stage];
   const double* wpos = sm + L.wpos[stage];
   const double* wrot = sm + L.wrot[stage];
-  // (a) lane = task: M_k = -Jl^-1(e_k) (blocks -A, -B), weighted residual, LM term
   double mu = 0.0;
   if (lane < K) {
     const double* e = sm + L.e + 6 * lane;
     double ee[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ee[r] = e[r];
+    const double* ax = sm + L.eaux + 3 * lane;
+    const double aux[3] = {ax[0], ax[1], ax[2]};
     m3 A, B;
-    se3_jlinv(ee, A, B);
+    se3_jlinv_aux(ee, aux, A, B);
     double* M = sm + L.M + 18 * lane;
 #pragma unroll
     for (int i = 0; i < 9; i++) { M[i] = -A.a[i]; M[9 + i] = -B.a[i]; }
@@ -203,14 +223,21 @@ __device__ __forceinline__ void build_qp_wave(const IkLayout& L, double* sm, int
   mu = lm_damping * wave_sum(mu);
   WSYNC();
   PROF_END(pr, PH_JLOG);
-  PROF_BEGIN(pr);
-  // (b) lane = (task, dof) pair: weighted task-Jacobian column W_k * (-Jl^-1(e_k)) * J_body[:, d]
+  return mu;
+}
+
+// (b) virtual lane = (task, dof) pair: weighted task-Jacobian column W_k * (-Jl^-1(e_k)) * J_body[:, d]
+__device__ __forceinline__ void pairs_phase(const IkLayout& L, double* sm, int stage, const StageTabs& tb,
+                                            const short* hinge_body, int vlane, int nvl) {
+  const int P = L.P[stage];
+  const double* wpos = sm + L.wpos[stage];
+  const double* wrot = sm + L.wrot[stage];
   double* Jw = sm + L.Jw;
   double* cpart = sm + L.cpart;
   const double* X = sm + L.xa;
-  for (int p = lane; p < P; p += 64) {
-    int k = pair_task[p], dof = pair_dof[p];
-    int b = task_body[k];
+  for (int p = vlane; p < P; p += nvl) {
+    int k = tb.pair_task[p], dof = tb.pair_dof[p];
+    int b = tb.task_body[k];
     d3 pb = {X[7 * b], X[7 * b + 1], X[7 * b + 2]};
     d4 qb = {X[7 * b + 3], X[7 * b + 4], X[7 * b + 5], X[7 * b + 6]};
     d3 lin, ang;
@@ -248,14 +275,17 @@ __device__ __forceinline__ void build_qp_wave(const IkLayout& L, double* sm, int
     }
     cpart[p] = cp;   // this column's contribution to c = sum_k (W J_k)^T (W e_k)
   }
-  WSYNC();
-  PROF_END(pr, PH_PAIRS);
-  PROF_BEGIN(pr);
-  // (c) lane = dof: gather c; bounds of the limited hinges (mink ConfigurationLimit)
+}
+
+// (c) lane = dof: gather c; bounds of the limited hinges (mink ConfigurationLimit)
+__device__ __forceinline__ void cvec_phase(const IkLayout& L, double* sm, int stage, const StageTabs& tb,
+                                           const short* limited, double limit_gain, int lane) {
+  const int K = L.K[stage], nv = L.nv;
+  const double* cpart = sm + L.cpart;
   if (lane < nv) {
     int idx[GMR_MAX_TASKS];
 #pragma unroll
-    for (int k = 0; k < GMR_MAX_TASKS; k++) idx[k] = k < K ? (int)pair_index[k * nv + lane] : -1;
+    for (int k = 0; k < GMR_MAX_TASKS; k++) idx[k] = k < K ? (int)tb.pair_index[k * nv + lane] : -1;
     double cc = 0.0;
 #pragma unroll
     for (int k = 0; k < GMR_MAX_TASKS; k++) cc += idx[k] >= 0 ? cpart[idx[k]] : 0.0;
@@ -269,61 +299,121 @@ __device__ __forceinline__ void build_qp_wave(const IkLayout& L, double* sm, int
     (sm + L.lo)[lane] = lo;
     (sm + L.hi)[lane] = hi;
   }
-  PROF_END(pr, PH_CVEC);
-  PROF_BEGIN(pr);
-  // (d) H: every lane sums the terms of the entries it owns (static schedule) and stores each once.
-  // Two terms per trip, operands of both loaded before any store (Jw is read-only here, H write-only).
-  {
-    double* __restrict__ H = sm + L.H;
-    const double* __restrict__ J = sm + L.Jw;
-    const double diag = damping + mu;
-    const int i1 = istart[lane + 1];
-    int it = istart[lane];
-    double acc = 0.0;
-    for (; it + 1 < i1; it += 2) {
-      const uint32_t w0 = items[it], w1 = items[it + 1];
-      const double* a0 = J + 6 * (w0 & 511u);
-      const double* b0 = J + 6 * ((w0 >> 9) & 511u);
-      const double* a1 = J + 6 * (w1 & 511u);
-      const double* b1 = J + 6 * ((w1 >> 9) & 511u);
-      double x0[6], y0[6], x1[6], y1[6];
+}
+
+// (d) H: every (virtual) lane sums the terms of the entries it owns (static schedule) and stores each
+// once.  Two terms per trip, operands of both loaded before any store (Jw read-only, H write-only).
+__device__ __forceinline__ void hacc_phase(const IkLayout& L, double* sm, const StageTabs& tb, double diag,
+                                           int vlane) {
+  const int ldh = L.ldh;
+  double* __restrict__ H = sm + L.H;
+  const double* __restrict__ J = sm + L.Jw;
+  const uint32_t* items = tb.items;
+  const int i1 = tb.istart[vlane + 1];
+  int it = tb.istart[vlane];
+  double acc = 0.0;
+  uint32_t n0 = it < i1 ? items[it] : 0u, n1 = it + 1 < i1 ? items[it + 1] : 0u;
+  for (; it + 1 < i1; it += 2) {
+    const uint32_t w0 = n0, w1 = n1;
+    n0 = it + 2 < i1 ? items[it + 2] : 0u;   // next trip's item words are in flight during this one
+    n1 = it + 3 < i1 ? items[it + 3] : 0u;
+    const double* a0 = J + 6 * (w0 & 511u);
+    const double* b0 = J + 6 * ((w0 >> 9) & 511u);
+    const double* a1 = J + 6 * (w1 & 511u);
+    const double* b1 = J + 6 * ((w1 >> 9) & 511u);
+    double x0[6], y0[6], x1[6], y1[6];
 #pragma unroll
-      for (int r = 0; r < 6; r++) { x0[r] = a0[r]; y0[r] = b0[r]; x1[r] = a1[r]; y1[r] = b1[r]; }
-      double s0 = (x0[0] * y0[0] + x0[1] * y0[1] + x0[2] * y0[2]) + (x0[3] * y0[3] + x0[4] * y0[4] + x0[5] * y0[5]);
-      double s1 = (x1[0] * y1[0] + x1[1] * y1[1] + x1[2] * y1[2]) + (x1[3] * y1[3] + x1[4] * y1[4] + x1[5] * y1[5]);
-      if ((w0 >> 30) & 1u) s0 = 0.0;
-      if ((w1 >> 30) & 1u) s1 = 0.0;
-      acc += s0;
-      if (w0 >> 31) {
-        int da = (w0 >> 18) & 63u, db = (w0 >> 24) & 63u;
-        double v = acc + (da == db ? diag : 0.0);
-        H[da * ldh + db] = v;
-        H[db * ldh + da] = v;
-        acc = 0.0;
-      }
-      acc += s1;
-      if (w1 >> 31) {
-        int da = (w1 >> 18) & 63u, db = (w1 >> 24) & 63u;
-        double v = acc + (da == db ? diag : 0.0);
-        H[da * ldh + db] = v;
-        H[db * ldh + da] = v;
-        acc = 0.0;
-      }
+    for (int r = 0; r < 6; r++) { x0[r] = a0[r]; y0[r] = b0[r]; x1[r] = a1[r]; y1[r] = b1[r]; }
+    double s0 = (x0[0] * y0[0] + x0[1] * y0[1] + x0[2] * y0[2]) + (x0[3] * y0[3] + x0[4] * y0[4] + x0[5] * y0[5]);
+    double s1 = (x1[0] * y1[0] + x1[1] * y1[1] + x1[2] * y1[2]) + (x1[3] * y1[3] + x1[4] * y1[4] + x1[5] * y1[5]);
+    if ((w0 >> 30) & 1u) s0 = 0.0;
+    if ((w1 >> 30) & 1u) s1 = 0.0;
+    acc += s0;
+    if (w0 >> 31) {
+      int da = (w0 >> 18) & 63u, db = (w0 >> 24) & 63u;
+      double v = acc + (da == db ? diag : 0.0);
+      H[da * ldh + db] = v;
+      H[db * ldh + da] = v;
+      acc = 0.0;
     }
-    if (it < i1) {
-      const uint32_t w0 = items[it];
-      double s0 = ((w0 >> 30) & 1u) ? 0.0 : dot6(J + 6 * (w0 & 511u), J + 6 * ((w0 >> 9) & 511u));
-      acc += s0;
-      if (w0 >> 31) {
-        int da = (w0 >> 18) & 63u, db = (w0 >> 24) & 63u;
-        double v = acc + (da == db ? diag : 0.0);
-        H[da * ldh + db] = v;
-        H[db * ldh + da] = v;
-      }
+    acc += s1;
+    if (w1 >> 31) {
+      int da = (w1 >> 18) & 63u, db = (w1 >> 24) & 63u;
+      double v = acc + (da == db ? diag : 0.0);
+      H[da * ldh + db] = v;
+      H[db * ldh + da] = v;
+      acc = 0.0;
     }
   }
-  WSYNC();
-  PROF_END(pr, PH_HACC);
+  if (it < i1) {
+    const uint32_t w0 = n0;
+    double s0 = ((w0 >> 30) & 1u) ? 0.0 : dot6(J + 6 * (w0 & 511u), J + 6 * ((w0 >> 9) & 511u));
+    acc += s0;
+    if (w0 >> 31) {
+      int da = (w0 >> 18) & 63u, db = (w0 >> 24) & 63u;
+      double v = acc + (da == db ? diag : 0.0);
+      H[da * ldh + db] = v;
+      H[db * ldh + da] = v;
+    }
+  }
+}
+
+// the whole assembly as seen from the MAIN wave.  NW == 1: all four phases by this wave.  NW > 1:
+// the Jacobian columns are shared by all NW waves, then the helpers assemble H (64*(NW-1) virtual
+// lanes) while this wave gathers c and the bounds; three workgroup barriers per assembly.
+template <int NW>
+__device__ __forceinline__ void build_qp_main(const IkLayout& L, double* sm, int stage, const StageTabs& tb,
+                                              const short* hinge_body, const short* limited, int* ctl,
+                                              double damping, double lm_damping, double limit_gain, int lane,
+                                              Prof& pr) {
+  double mu = jlog_phase<NW>(L, sm, stage, lm_damping, lane, pr);
+  const double diag = damping + mu;
+  if (NW == 1) {
+    PROF_BEGIN(pr);
+    pairs_phase(L, sm, stage, tb, hinge_body, lane, 64);
+    WSYNC();
+    PROF_END(pr, PH_PAIRS);
+    PROF_BEGIN(pr);
+    cvec_phase(L, sm, stage, tb, limited, limit_gain, lane);
+    PROF_END(pr, PH_CVEC);
+    PROF_BEGIN(pr);
+    hacc_phase(L, sm, tb, diag, lane);
+    WSYNC();
+    PROF_END(pr, PH_HACC);
+  } else {
+    PROF_BEGIN(pr);
+    if (lane == 0) { ctl[0] = CMD_BUILD; ctl[1] = stage; (sm + L.scal)[0] = diag; }
+    __syncthreads();                      // B1: helpers see the command, M / we / FK state are final
+    pairs_phase(L, sm, stage, tb, hinge_body, lane, 64 * NW);
+    __syncthreads();                      // B2: all Jacobian columns written
+    PROF_END(pr, PH_PAIRS);
+    PROF_BEGIN(pr);
+    cvec_phase(L, sm, stage, tb, limited, limit_gain, lane);
+    PROF_END(pr, PH_CVEC);
+    PROF_BEGIN(pr);
+    __syncthreads();                      // B3: H complete (helpers)
+    PROF_END(pr, PH_HACC);
+  }
+}
+
+// helper waves (NW > 1): serve assembly requests until the main wave says EXIT
+template <int NW>
+__device__ __forceinline__ void helper_loop(const IkLayout& L, double* sm, const uint32_t* sw, const short* si,
+                                            const short* hinge_body, const int* ctl, int wave, int lane) {
+  for (;;) {
+    __syncthreads();                      // B1 (or the EXIT barrier)
+    const int cmd = ctl[0];
+    if (cmd == CMD_EXIT) return;
+    const int stage = ctl[1];
+    const double diag = (sm + L.scal)[0];
+    StageTabs tb = {si + L.i_task_body[stage], si + L.i_task_human[stage], si + L.i_pair_task[stage],
+                    si + L.i_pair_dof[stage], si + L.i_pair_index[stage], sw + L.w_items[stage],
+                    reinterpret_cast<const int*>(sw + L.w_istart[stage])};
+    pairs_phase(L, sm, stage, tb, hinge_body, wave * 64 + lane, 64 * NW);
+    __syncthreads();                      // B2
+    hacc_phase(L, sm, tb, diag, (wave - 1) * 64 + lane);
+    __syncthreads();                      // B3
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -333,7 +423,7 @@ __device__ __forceinline__ void build_qp_wave(const IkLayout& L, double* sm, int
 // identity.  `st` (0 free, -1 at lower, +1 at upper) is carried from solve to solve (warm start).
 // Returns 0 ok / <0 failure; the solution is left in sm[L.x].
 // ---------------------------------------------------------------------------------------------
-template <int NVP>
+template <int NVP, int NW>
 __device__ __forceinline__ int solve_qp_regs(const IkLayout& L, double* sm, int lane, int& st, Prof& pr) {
   constexpr int LDK = NVP + 1;
   const int n = L.nv, ldh = L.ldh;
@@ -475,6 +565,7 @@ __device__ __forceinline__ int solve_qp_regs(const IkLayout& L, double* sm, int 
 // ---------------------------------------------------------------------------------------------
 // mj_integratePos with v = dq/dt (App. A.7): lane 0 the free joint, lane 6+h hinge h
 // ---------------------------------------------------------------------------------------------
+template <int NW>
 __device__ __forceinline__ void integrate_wave(const IkLayout& L, double* sm, double dt, int lane, Prof& pr) {
   PROF_BEGIN(pr);
   double* q = sm + L.q;
@@ -500,6 +591,7 @@ __device__ __forceinline__ void integrate_wave(const IkLayout& L, double* sm, do
 // ---------------------------------------------------------------------------------------------
 // target preprocessing (motion_retarget.py:203-270).  lane b < nhuman.
 // ---------------------------------------------------------------------------------------------
+template <int NW>
 __device__ __forceinline__ void preprocess_wave(const IkLayout& L, double* sm, const short* is_foot, int human_root,
                                                 double ground_offset, int flags, int lane, Prof& pr) {
   PROF_BEGIN(pr);
@@ -542,17 +634,18 @@ __device__ __forceinline__ void preprocess_wave(const IkLayout& L, double* sm, c
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
-template <int NVP>
-__global__ __launch_bounds__(64) void ik_streams_kernel(const uint4* __restrict__ image, IkLayout L, IkParams P,
-                                                        int S, int T,
-                                                        const double* __restrict__ q0,
-                                                        const double* __restrict__ human,
-                                                        const int32_t* __restrict__ len, int flags,
-                                                        double* __restrict__ q_out, int32_t* __restrict__ nsolve,
-                                                        int32_t* __restrict__ status,
-                                                        unsigned long long* __restrict__ prof_out) {
+template <int NVP, int NW>
+__global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __restrict__ image, IkLayout L, IkParams P,
+                                                             int S, int T, const double* __restrict__ q0,
+                                                             const double* __restrict__ human,
+                                                             const int32_t* __restrict__ len, int flags,
+                                                             double* __restrict__ q_out,
+                                                             int32_t* __restrict__ nsolve,
+                                                             int32_t* __restrict__ status,
+                                                             unsigned long long* __restrict__ prof_out) {
   extern __shared__ __align__(16) double smem[];
-  const int lane = threadIdx.x;
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   const int s = blockIdx.x;
   if (s >= S) return;
   double* sm = smem;
@@ -563,6 +656,7 @@ __global__ __launch_bounds__(64) void ik_streams_kernel(const uint4* __restrict_
 #endif
   uint32_t* sw = reinterpret_cast<uint32_t*>(smem + L.n_double);
   short* si = reinterpret_cast<short*>(sw + L.n_word);
+  int* ctl = reinterpret_cast<int*>(sw + L.w_ctl);
   short* hop = si + L.i_hop;
   short* depth = si + L.i_depth;
   short* body_hinge = si + L.i_body_hinge;
@@ -575,17 +669,21 @@ __global__ __launch_bounds__(64) void ik_streams_kernel(const uint4* __restrict_
   {
     uint4* dst = reinterpret_cast<uint4*>(smem);
     const int n16 = (L.smem_bytes + 15) >> 4;
-    for (int i = lane; i < n16; i += 64) dst[i] = image[i];
+    for (int i = threadIdx.x; i < n16; i += 64 * NW) dst[i] = image[i];
+  }
+  __syncthreads();
+  if (NW > 1 && wave > 0) {
+    helper_loop<NW>(L, sm, sw, si, hinge_body, ctl, wave, lane);
+    return;
   }
   const double damping = P.damping, lm_damping = P.lm_damping, tol = P.tol, limit_gain = P.limit_gain;
   const double ground_offset = P.ground_offset, dt = P.dt;
   const int max_iter = P.max_iter, human_root = P.human_root;
   const int use0 = P.use0, use1 = P.use1;
-  WSYNC();
 
   for (int i = lane; i < nq; i += 64) (sm + L.q)[i] = q0[(size_t)s * nq + i];
   WSYNC();
-  fk_wave(L, sm, hop, depth, body_hinge, lane, pr);
+  fk_wave<NW>(L, sm, hop, depth, body_hinge, lane, pr);
 
   const int Ts = len ? min(len[s], T) : T;
   const size_t fstride = (size_t)nhum * 7;
@@ -611,11 +709,12 @@ __global__ __launch_bounds__(64) void ik_streams_kernel(const uint4* __restrict_
     WSYNC();
     int ns0 = 0, ns1 = 0;
     if (stat == GMR_STATUS_OK) {
-      preprocess_wave(L, sm, is_foot, human_root, ground_offset, flags, lane, pr);
+      preprocess_wave<NW>(L, sm, is_foot, human_root, ground_offset, flags, lane, pr);
       for (int stage = 0; stage < 2; stage++) {
         if (!(stage == 0 ? use0 : use1)) continue;
-        const short* tb = si + L.i_task_body[stage];
-        const short* th = si + L.i_task_human[stage];
+        const StageTabs tb = {si + L.i_task_body[stage], si + L.i_task_human[stage], si + L.i_pair_task[stage],
+                              si + L.i_pair_dof[stage], si + L.i_pair_index[stage], sw + L.w_items[stage],
+                              reinterpret_cast<const int*>(sw + L.w_istart[stage])};
         const int K = L.K[stage];
         if (h_stage != stage) {
           // structural zeros of H are never written by the schedule: clear when the pattern changes
@@ -623,19 +722,16 @@ __global__ __launch_bounds__(64) void ik_streams_kernel(const uint4* __restrict_
           h_stage = stage;
           WSYNC();
         }
-        double curr = errors_wave(L, sm, tb, th, K, lane, pr);
+        double curr = errors_wave<NW>(L, sm, tb.task_body, tb.task_human, K, lane, pr);
         int nsol = 0, num_iter = 0;
         for (;;) {
-          build_qp_wave(L, sm, stage, tb, si + L.i_pair_task[stage], si + L.i_pair_dof[stage],
-                        si + L.i_pair_index[stage], hinge_body, limited, sw + L.w_items[stage],
-                        reinterpret_cast<const int*>(sw + L.w_istart[stage]), damping, lm_damping, limit_gain,
-                        lane, pr);
+          build_qp_main<NW>(L, sm, stage, tb, hinge_body, limited, ctl, damping, lm_damping, limit_gain, lane, pr);
           PROF_COUNT(pr, PH_NSOLVE);
-          int rc = solve_qp_regs<NVP>(L, sm, lane, qp_state, pr);
+          int rc = solve_qp_regs<NVP, NW>(L, sm, lane, qp_state, pr);
           if (rc != GMR_STATUS_OK) { stat = rc; break; }
-          integrate_wave(L, sm, dt, lane, pr);
-          fk_wave(L, sm, hop, depth, body_hinge, lane, pr);
-          double next = errors_wave(L, sm, tb, th, K, lane, pr);
+          integrate_wave<NW>(L, sm, dt, lane, pr);
+          fk_wave<NW>(L, sm, hop, depth, body_hinge, lane, pr);
+          double next = errors_wave<NW>(L, sm, tb.task_body, tb.task_human, K, lane, pr);
           nsol++;
           if (nsol > 1) num_iter++;
           if (!(curr - next > tol && num_iter < max_iter)) break;
@@ -651,6 +747,10 @@ __global__ __launch_bounds__(64) void ik_streams_kernel(const uint4* __restrict_
     WSYNC();
   }
   if (lane == 0) status[s] = stat;
+  if (NW > 1) {                           // release the helper waves
+    if (lane == 0) ctl[0] = CMD_EXIT;
+    __syncthreads();
+  }
 #ifdef GMR_IK_PROFILE
   pr.acc[PH_TICKS] = __builtin_amdgcn_s_memtime() - k_t0;
   pr.acc[PH_REALTIME] = __builtin_amdgcn_s_memrealtime() - k_r0;
@@ -663,39 +763,53 @@ __global__ __launch_bounds__(64) void ik_streams_kernel(const uint4* __restrict_
 
 }  // namespace gmr
 
-// host-side launcher used by gmr_abi.hip
-template <int NVP>
+// host-side launchers used by gmr_abi.hip.  NW = 1: one wave per stream (throughput shape, many
+// streams); NW = 4: one main wave + 3 helpers per stream (latency shape: fewer streams than the chip
+// has SIMDs, the helpers share the two wide assembly phases).
+template <int NVP, int NW>
 static hipError_t launch_nvp(const uint4* d_image, const gmr::IkLayout* L, const gmr::IkParams* P, int S, int T,
                              const double* d_q0, const double* d_human,
                              const int32_t* d_len, int flags, double* d_q_out, int32_t* d_nsolve, int32_t* d_status,
                              hipStream_t stream, unsigned long long* d_prof) {
-  hipLaunchKernelGGL(gmr::ik_streams_kernel<NVP>, dim3(S), dim3(64), L->smem_bytes, stream, d_image, *L, *P, S, T,
-                     d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, d_prof);
+  hipLaunchKernelGGL((gmr::ik_streams_kernel<NVP, NW>), dim3(S), dim3(64 * NW), L->smem_bytes, stream, d_image, *L,
+                     *P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, d_prof);
   return hipGetLastError();
 }
 
+#define GMR_DISPATCH(NVP_)                                                                                       \
+  case NVP_:                                                                                                     \
+    return L->nw == 1 ? launch_nvp<NVP_, 1>(d_image, L, P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, \
+                                            d_status, stream, d_prof)                                            \
+                      : launch_nvp<NVP_, 4>(d_image, L, P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, \
+                                            d_status, stream, d_prof);
+
 extern "C" hipError_t gmr_launch_ik_streams(const uint4* d_image, const gmr::IkLayout* L, const gmr::IkParams* P,
                                             int S, int T, const double* d_q0, const double* d_human,
-                                            const int32_t* d_len,
-                                            int flags, double* d_q_out, int32_t* d_nsolve, int32_t* d_status,
-                                            hipStream_t stream, unsigned long long* d_prof) {
+                                            const int32_t* d_len, int flags, double* d_q_out, int32_t* d_nsolve,
+                                            int32_t* d_status, hipStream_t stream, unsigned long long* d_prof) {
   if (S <= 0 || T <= 0) return hipSuccess;
   switch (L->nvp) {
-    case 28: return launch_nvp<28>(d_image, L, P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream, d_prof);
-    case 32: return launch_nvp<32>(d_image, L, P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream, d_prof);
-    case 36: return launch_nvp<36>(d_image, L, P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream, d_prof);
-    case 48: return launch_nvp<48>(d_image, L, P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream, d_prof);
+    GMR_DISPATCH(28)
+    GMR_DISPATCH(32)
+    GMR_DISPATCH(36)
+    GMR_DISPATCH(48)
     default: return hipErrorInvalidValue;
   }
 }
 
-extern "C" hipError_t gmr_ik_set_max_smem(int nvp, int bytes) {
+#define GMR_ATTR(NVP_)                                                                                  \
+  case NVP_:                                                                                            \
+    f = nw == 1 ? reinterpret_cast<const void*>(gmr::ik_streams_kernel<NVP_, 1>)                        \
+                : reinterpret_cast<const void*>(gmr::ik_streams_kernel<NVP_, 4>);                       \
+    break;
+
+extern "C" hipError_t gmr_ik_set_max_smem(int nvp, int nw, int bytes) {
   const void* f = nullptr;
   switch (nvp) {
-    case 28: f = reinterpret_cast<const void*>(gmr::ik_streams_kernel<28>); break;
-    case 32: f = reinterpret_cast<const void*>(gmr::ik_streams_kernel<32>); break;
-    case 36: f = reinterpret_cast<const void*>(gmr::ik_streams_kernel<36>); break;
-    case 48: f = reinterpret_cast<const void*>(gmr::ik_streams_kernel<48>); break;
+    GMR_ATTR(28)
+    GMR_ATTR(32)
+    GMR_ATTR(36)
+    GMR_ATTR(48)
     default: return hipErrorInvalidValue;
   }
   return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

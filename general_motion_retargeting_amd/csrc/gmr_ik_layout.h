@@ -15,15 +15,15 @@ constexpr int IK_MAX_HOPS = 5;  // pointer-jumping rounds of the FK: 2^5 = 32 > 
 
 struct IkLayout {
   // dimensions
-  int nb, nh, nq, nv, nvp, nhum, maxd, nhop, ldh;
+  int nb, nh, nq, nv, nvp, nw, nhum, maxd, nhop, ldh;
   int K[2], P[2], nitem[2];
   // offsets in doubles
   int body_pos, body_quat, axis, range_lo, range_hi, scale, pos_off, quat_off;
   int wpos[2], wrot[2];
-  int q, xa, xb, xaxis, raw, tgt, e, we, M, Jw, cpart, H, Kt, c, x, lo, hi;
+  int q, xa, xb, xaxis, raw, tgt, e, eaux, we, M, Jw, cpart, H, Kt, c, x, lo, hi, scal;
   int n_double;
   // offsets in 32-bit words (after the doubles): the H-assembly schedule
-  int w_items[2], w_istart[2];
+  int w_items[2], w_istart[2], w_ctl;
   int n_word;
   // offsets in shorts (after the words)
   int i_hop, i_depth, i_body_hinge, i_hinge_body, i_limited, i_is_foot;
@@ -51,12 +51,14 @@ inline int ik_padded_nv(int nv) {
 //            [31] last term of the entry
 // ---------------------------------------------------------------------------------------------
 struct IkSchedule {
+  int nlanes;                      // virtual lanes that share the assembly: 64 (one wave) or 192 (3 helpers)
   std::vector<uint32_t> items[2];
-  int istart[2][65];
+  std::vector<int> istart[2];      // nlanes + 1 offsets
 };
 
-inline IkSchedule make_ik_schedule(const gmr_model_t& m, const gmr_taskset_t& ts) {
+inline IkSchedule make_ik_schedule(const gmr_model_t& m, const gmr_taskset_t& ts, int nlanes) {
   IkSchedule sch;
+  sch.nlanes = nlanes;
   const int nv = m.nv;
   for (int s = 0; s < 2; s++) {
     std::vector<std::vector<uint32_t>> terms((size_t)nv * nv);
@@ -76,16 +78,17 @@ inline IkSchedule make_ik_schedule(const gmr_model_t& m, const gmr_taskset_t& ts
         if (w > 0 || da == db) ents.push_back({da, db, w});
       }
     std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.w > y.w; });
-    std::vector<std::vector<Ent>> per_lane(64);
-    int load[64] = {0};
+    std::vector<std::vector<Ent>> per_lane(nlanes);
+    std::vector<int> load(nlanes, 0);
     for (const Ent& e : ents) {
       int best = 0;
-      for (int l = 1; l < 64; l++) if (load[l] < load[best]) best = l;
+      for (int l = 1; l < nlanes; l++) if (load[l] < load[best]) best = l;
       per_lane[best].push_back(e);
       load[best] += std::max(e.w, 1) + 1;  // +1: the two stores of the entry
     }
     sch.items[s].clear();
-    for (int l = 0; l < 64; l++) {
+    sch.istart[s].assign(nlanes + 1, 0);
+    for (int l = 0; l < nlanes; l++) {
       sch.istart[s][l] = (int)sch.items[s].size();
       for (const Ent& e : per_lane[l]) {
         const auto& t = terms[(size_t)e.da * nv + e.db];
@@ -95,13 +98,14 @@ inline IkSchedule make_ik_schedule(const gmr_model_t& m, const gmr_taskset_t& ts
           sch.items[s].push_back(t[i] | dd | (i + 1 == t.size() ? (1u << 31) : 0u));
       }
     }
-    sch.istart[s][64] = (int)sch.items[s].size();
+    sch.istart[s][nlanes] = (int)sch.items[s].size();
   }
   return sch;
 }
 
-inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, const IkSchedule& sch) {
+inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, const IkSchedule& sch, int nw) {
   IkLayout L{};
+  L.nw = nw;
   L.nb = m.nbody; L.nh = m.nhinge; L.nq = m.nq; L.nv = m.nv; L.nhum = ts.nhuman;
   L.nvp = ik_padded_nv(m.nv);
   int maxd = 1;
@@ -123,14 +127,15 @@ inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, co
   L.xa = D(7 * L.nb + 1); L.xb = D(7 * L.nb + 1);   // ping-pong (pos, quat) of the FK rounds
   L.xaxis = D(3 * L.nb);
   L.raw = D(7 * L.nhum + 1); L.tgt = D(7 * L.nhum + 1);
-  L.e = D(6 * Kmax); L.we = D(6 * Kmax); L.M = D(18 * Kmax); L.Jw = D(6 * Pmax); L.cpart = D(Pmax);
+  L.e = D(6 * Kmax); L.eaux = D(3 * Kmax); L.we = D(6 * Kmax); L.M = D(18 * Kmax); L.Jw = D(6 * Pmax); L.cpart = D(Pmax);
   L.H = D(L.nv * L.ldh + 2);
   L.Kt = D(L.nvp * (L.nvp + 1));
-  L.c = D(L.nv); L.x = D(L.nv); L.lo = D(L.nv); L.hi = D(L.nv);
+  L.c = D(L.nv); L.x = D(L.nv); L.lo = D(L.nv); L.hi = D(L.nv); L.scal = D(2);
   L.n_double = o;
   int w = 0;
   auto W = [&](int n) { int r = w; w += n; return r; };
-  for (int s = 0; s < 2; s++) { L.w_items[s] = W(L.nitem[s]); L.w_istart[s] = W(65); }
+  for (int s = 0; s < 2; s++) { L.w_items[s] = W(L.nitem[s]); L.w_istart[s] = W(sch.nlanes + 1); }
+  L.w_ctl = W(2);
   if (w % 2) w++;
   L.n_word = w;
   int i = 0;
@@ -196,7 +201,7 @@ inline std::vector<char> make_ik_image(const gmr_model_t& m, const gmr_taskset_t
   }
   for (int s = 0; s < 2; s++) {
     for (size_t i = 0; i < sch.items[s].size(); i++) sw[L.w_items[s] + i] = sch.items[s][i];
-    for (int l = 0; l < 65; l++) sw[L.w_istart[s] + l] = (uint32_t)sch.istart[s][l];
+    for (int l = 0; l <= sch.nlanes; l++) sw[L.w_istart[s] + l] = (uint32_t)sch.istart[s][l];
     for (int k = 0; k < L.K[s]; k++) {
       si[L.i_task_body[s] + k] = (short)ts.task_body[s][k];
       si[L.i_task_human[s] + k] = (short)ts.task_human[s][k];

@@ -69,6 +69,10 @@ int gmr_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on
 int gmr_solver_create(const gmr_model_t* model, const gmr_taskset_t* taskset, gmr_solver_t** out);
 int gmr_solver_destroy(gmr_solver_t* solver);
 int gmr_solver_dims(const gmr_solver_t* solver, int* nq, int* nv, int* nhuman);
+/* Launch shape of the IK kernel: 1 = one wavefront per stream (most streams resident), 4 = one main
+ * wavefront + 3 helper wavefronts per stream (shortest per-frame latency), 0 = automatic (4 up to 768
+ * streams per launch, 1 above).  Results agree to rounding between the shapes; no reference analogue. */
+int gmr_solver_set_waves(gmr_solver_t* solver, int waves_per_stream);
 
 /* ---- H2-H7: the retargeting loop ---------------------------------------------------------- */
 /* Replaces the caller loop `for frame in frames: qpos = retargeter.retarget(frame)`

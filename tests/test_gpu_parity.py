@@ -322,3 +322,29 @@ def test_generic_large_robot_nvp48(hip, oracle, tmp_path):
     assert (st_h == 0).all() and (st_o == 0).all() and np.array_equal(ns_h, ns_o)
     joint, pos, rot = _compare(q_h, q_o)
     assert joint <= 1e-8 and pos <= 1e-8 and rot <= 1e-8, (joint, pos, rot)
+
+
+def test_launch_shapes_agree(hip, oracle, g1):
+    """1 wave per stream (many streams) and main + 3 helper waves per stream (few streams) are the same
+    algorithm: identical solve counts, results equal to rounding; automatic choice by stream count."""
+    from general_motion_retargeting_amd import synth
+    human, q0 = synth.make_streams(g1.model, g1.tt, 12, 8, seed=77)
+    sol = hip.Solver(g1.mb, g1.ts)
+    sol.set_waves(1)
+    q1, ns1, st1 = sol.retarget_streams(q0, human)
+    sol.set_waves(4)
+    q4, ns4, st4 = sol.retarget_streams(q0, human)
+    sol.set_waves(0)
+    qa, nsa, _ = sol.retarget_streams(q0, human)
+    assert (st1 == 0).all() and (st4 == 0).all()
+    assert np.array_equal(ns1, ns4) and np.abs(q1 - q4).max() <= 1e-12
+    assert np.array_equal(qa, q4)                                # 12 streams -> helper shape
+    q_o, ns_o, _ = oracle.retarget_streams(g1.mb, g1.ts, q0, human)
+    assert np.array_equal(ns1, ns_o) and np.abs(q1 - q_o).max() <= TOL_RAD
+    # above the threshold the one-wave shape is chosen: 800 copies of one short stream
+    hb = np.repeat(human[:1, :3], 800, axis=0)
+    qb0 = np.repeat(q0[:1], 800, axis=0)
+    qb, nsb, stb = sol.retarget_streams(qb0, hb)
+    assert (stb == 0).all() and np.array_equal(qb[0], qb[799]) and np.abs(qb[0] - q1[0, :3]).max() <= 1e-12
+    with pytest.raises(hip.GmrHipError):
+        sol.set_waves(3)
