@@ -23,10 +23,21 @@ __device__ __forceinline__ d4 qmul(d4 a, d4 b) {
           a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
           a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
 }
+// 1/sqrt(x) for a normal-range positive x (pivots of an SPD matrix, squared quaternion norms):
+// v_rsq_f64 seed + two Newton steps, no range scaling / special-case handling -> ~1 ulp, a third of
+// the dependent latency of the library rsqrt.  NaN / non-positive inputs stay NaN (callers test).
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  y = y * fma(-h * y, y, 1.5);
+  y = y * fma(-h * y, y, 1.5);
+  return y;
+}
+
 __device__ __forceinline__ d4 qconj(d4 a) { return {a.w, -a.x, -a.y, -a.z}; }
 __device__ __forceinline__ d4 qnormalize(d4 a) {
   double n2 = a.w * a.w + a.x * a.x + a.y * a.y + a.z * a.z;
-  double s = rsqrt(n2);
+  double s = fast_rsqrt(n2);
   return {a.w * s, a.x * s, a.y * s, a.z * s};
 }
 // rotate v by unit quaternion q: v + 2 w (u x v) + 2 u x (u x v)

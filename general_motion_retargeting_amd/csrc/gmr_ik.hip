@@ -52,7 +52,7 @@ __device__ __forceinline__ void wsync() {
 }
 #define WSYNC() wsync<NW>()
 
-enum { CMD_BUILD = 1, CMD_EXIT = 2 };
+enum { CMD_BUILD = 1, CMD_EXIT = 2 };   // CMD_BUILD: assemble the QP, then (tree solver) solve it together
 
 // Diagnostic phase timer (GMR_IK_PROFILE builds only; never in the shipped kernel): s_memtime
 // stamps accumulated per phase, written to a buffer no other code reads.
@@ -86,6 +86,10 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
 __device__ __forceinline__ double dot6(const double* a, const double* b) {
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
 }
+
+}  // namespace gmr
+#include "gmr_ik_tree.h"
+namespace gmr {
 
 // ---------------------------------------------------------------------------------------------
 // FK: mj_kinematics semantics (App. A.3), evaluated by pointer jumping.  lane b < nb.
@@ -400,6 +404,7 @@ __device__ __forceinline__ void build_qp_main(const IkLayout& L, double* sm, int
 template <int NW>
 __device__ __forceinline__ void helper_loop(const IkLayout& L, double* sm, const uint32_t* sw, const short* si,
                                             const short* hinge_body, const int* ctl, int wave, int lane) {
+  TreeState bs = {0ull, 0ull};            // bound sets of the QP (identical in every wavefront)
   for (;;) {
     __syncthreads();                      // B1 (or the EXIT barrier)
     const int cmd = ctl[0];
@@ -413,6 +418,7 @@ __device__ __forceinline__ void helper_loop(const IkLayout& L, double* sm, const
     __syncthreads();                      // B2
     hacc_phase(L, sm, tb, diag, (wave - 1) * 64 + lane);
     __syncthreads();                      // B3
+    if (L.tree_ok) { Prof hp; (void)solve_qp_tree(L, sm, const_cast<uint32_t*>(sw), si, wave, lane, bs, hp); }
   }
 }
 
@@ -474,7 +480,7 @@ __device__ __forceinline__ int solve_qp_regs(const IkLayout& L, double* sm, int 
     for (int j = 0; j < NVP; j++) {
       double dj = readlane_d(r[j], j);
       bad = bad || !(dj > 0.0);
-      double dinv = rsqrt(dj);
+      double dinv = fast_rsqrt(dj);
       double l = r[j] * dinv;
       r[j] = l;
       if (lane == j) mydinv = dinv;
@@ -690,6 +696,7 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
   const double* hs = human + (size_t)s * T * fstride;
   int stat = GMR_STATUS_OK;
   int qp_state = 0;     // this lane's bound state of the previous solve (QP warm start)
+  TreeState tree_state = {0ull, 0ull};
   int h_stage = -1;     // stage whose sparsity pattern H currently holds
   // first frame's raw targets
   double r0 = 0.0, r1 = 0.0;
@@ -727,7 +734,13 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
         for (;;) {
           build_qp_main<NW>(L, sm, stage, tb, hinge_body, limited, ctl, damping, lm_damping, limit_gain, lane, pr);
           PROF_COUNT(pr, PH_NSOLVE);
-          int rc = solve_qp_regs<NVP, NW>(L, sm, lane, qp_state, pr);
+          int rc;
+          if (NW > 1 && L.tree_ok) {
+            PROF_COUNT(pr, PH_NFACT);
+            rc = solve_qp_tree(L, sm, sw, si, 0, lane, tree_state, pr);   // helpers joined after barrier B3
+          } else {
+            rc = solve_qp_regs<NVP, NW>(L, sm, lane, qp_state, pr);
+          }
           if (rc != GMR_STATUS_OK) { stat = rc; break; }
           integrate_wave<NW>(L, sm, dt, lane, pr);
           fk_wave<NW>(L, sm, hop, depth, body_hinge, lane, pr);

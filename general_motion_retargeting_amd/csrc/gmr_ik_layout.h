@@ -16,17 +16,18 @@ constexpr int IK_MAX_HOPS = 5;  // pointer-jumping rounds of the FK: 2^5 = 32 > 
 struct IkLayout {
   // dimensions
   int nb, nh, nq, nv, nvp, nw, nhum, maxd, nhop, ldh;
+  int tree_ok, tree_nt;          // limb/trunk decomposition usable by the 4-wavefront tree solver
   int K[2], P[2], nitem[2];
   // offsets in doubles
   int body_pos, body_quat, axis, range_lo, range_hi, scale, pos_off, quat_off;
   int wpos[2], wrot[2];
-  int q, xa, xb, xaxis, raw, tgt, e, eaux, we, M, Jw, cpart, H, Kt, c, x, lo, hi, scal;
+  int q, xa, xb, xaxis, raw, tgt, e, eaux, we, M, Jw, cpart, H, Kt, c, x, lo, hi, scal, tr_spart, tr_rpart;
   int n_double;
   // offsets in 32-bit words (after the doubles): the H-assembly schedule
-  int w_items[2], w_istart[2], w_ctl;
+  int w_items[2], w_istart[2], w_ctl, w_tr_mask, w_tr_cnt;
   int n_word;
   // offsets in shorts (after the words)
-  int i_hop, i_depth, i_body_hinge, i_hinge_body, i_limited, i_is_foot;
+  int i_hop, i_depth, i_body_hinge, i_hinge_body, i_limited, i_is_foot, i_tree_limb, i_tree_trunk;
   int i_task_body[2], i_task_human[2], i_pair_task[2], i_pair_dof[2], i_pair_index[2];
   int n_short;
   int smem_bytes;
@@ -103,9 +104,75 @@ inline IkSchedule make_ik_schedule(const gmr_model_t& m, const gmr_taskset_t& ts
   return sch;
 }
 
+// Limb / trunk decomposition of the velocity dofs for the tree solver (gmr_ik_tree.h): limbs are the
+// maximal leaf chains below the last branching dof; everything above (floating base, waist) is the
+// trunk.  At most 4 limbs of <= 8 dofs are kept (the longest); shorter extra chains (a head) join the
+// trunk, which may hold <= 10 dofs.  limb[l][a] = dof or -1 (tip first), trunk[t] = dof or -1.
+struct IkTree {
+  bool ok;
+  int nt;
+  int limb[4][8];
+  int trunk[10];
+};
+
+inline IkTree make_ik_tree(const gmr_model_t& m) {
+  IkTree tr;
+  tr.ok = false; tr.nt = 0;
+  for (auto& l : tr.limb) for (int& d : l) d = -1;
+  for (int& d : tr.trunk) d = -1;
+  const int nv = m.nv;
+  std::vector<int> pd(nv, -1), cc(nv, 0);
+  for (int d = 1; d < 6; d++) pd[d] = d - 1;
+  for (int h = 0; h < m.nhinge; h++) {
+    int b = m.parent[m.hinge_body[h]], p = 5;
+    while (b > 0) {
+      if (m.body_hinge[b] >= 0) { p = 6 + m.body_hinge[b]; break; }
+      b = m.parent[b];
+    }
+    pd[6 + h] = p;
+  }
+  for (int d = 1; d < nv; d++) cc[pd[d]]++;
+  std::vector<char> intrunk(nv, 0);
+  for (int d = 0; d < 6; d++) intrunk[d] = 1;   // the floating base always belongs to the trunk
+  for (int d = 0; d < nv; d++)
+    if (cc[d] >= 2) for (int x = d; x >= 0; x = pd[x]) intrunk[x] = 1;
+  std::vector<std::vector<int>> limbs;
+  for (int d = 0; d < nv; d++)
+    if (cc[d] == 0 && !intrunk[d]) {
+      std::vector<int> ch;
+      for (int x = d; x >= 0 && !intrunk[x]; x = pd[x]) ch.push_back(x);
+      limbs.push_back(ch);
+    }
+  std::stable_sort(limbs.begin(), limbs.end(), [](const std::vector<int>& a, const std::vector<int>& b) { return a.size() > b.size(); });
+  std::vector<int> trunk;
+  for (int d = 0; d < nv; d++) if (intrunk[d]) trunk.push_back(d);
+  for (size_t l = 0; l < limbs.size(); l++) {
+    if (l < 4 && limbs[l].size() <= 8) continue;
+    for (int d : limbs[l]) trunk.push_back(d);     // surplus / over-long chains are solved densely in the trunk
+  }
+  if (trunk.size() > 10) return tr;
+  for (size_t l = 0; l < limbs.size() && l < 4; l++) {
+    if (limbs[l].size() > 8) continue;
+    for (size_t a = 0; a < limbs[l].size(); a++) tr.limb[l][a] = limbs[l][a];
+  }
+  std::sort(trunk.begin(), trunk.end());
+  for (size_t t = 0; t < trunk.size(); t++) tr.trunk[t] = trunk[t];
+  tr.nt = (int)trunk.size();
+  // every dof must be covered exactly once
+  std::vector<int> seen(nv, 0);
+  for (auto& l : tr.limb) for (int d : l) if (d >= 0) seen[d]++;
+  for (int d : tr.trunk) if (d >= 0) seen[d]++;
+  for (int d = 0; d < nv; d++) if (seen[d] != 1) return tr;
+  tr.ok = true;
+  return tr;
+}
+
 inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, const IkSchedule& sch, int nw) {
   IkLayout L{};
   L.nw = nw;
+  const IkTree tree = make_ik_tree(m);
+  L.tree_ok = (nw == 4 && tree.ok) ? 1 : 0;
+  L.tree_nt = tree.nt;
   L.nb = m.nbody; L.nh = m.nhinge; L.nq = m.nq; L.nv = m.nv; L.nhum = ts.nhuman;
   L.nvp = ik_padded_nv(m.nv);
   int maxd = 1;
@@ -129,19 +196,23 @@ inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, co
   L.raw = D(7 * L.nhum + 1); L.tgt = D(7 * L.nhum + 1);
   L.e = D(6 * Kmax); L.eaux = D(3 * Kmax); L.we = D(6 * Kmax); L.M = D(18 * Kmax); L.Jw = D(6 * Pmax); L.cpart = D(Pmax);
   L.H = D(L.nv * L.ldh + 2);
-  L.Kt = D(L.nvp * (L.nvp + 1));
+  L.Kt = D(std::max(L.nvp * (L.nvp + 1), nw == 4 ? 4 * 18 * 19 : 0));   // dense transpose / 4 tree-solver scratches
   L.c = D(L.nv); L.x = D(L.nv); L.lo = D(L.nv); L.hi = D(L.nv); L.scal = D(2);
+  L.tr_spart = D(nw == 4 ? 4 * 10 * 10 : 0); L.tr_rpart = D(nw == 4 ? 4 * 10 : 0);
   L.n_double = o;
   int w = 0;
   auto W = [&](int n) { int r = w; w += n; return r; };
   for (int s = 0; s < 2; s++) { L.w_items[s] = W(L.nitem[s]); L.w_istart[s] = W(sch.nlanes + 1); }
   L.w_ctl = W(2);
   if (w % 2) w++;
+  L.w_tr_mask = W(16); L.w_tr_cnt = W(4);
+  if (w % 2) w++;
   L.n_word = w;
   int i = 0;
   auto I = [&](int n) { int r = i; i += n; return r; };
   L.i_hop = I(IK_MAX_HOPS * L.nb); L.i_depth = I(L.nb); L.i_body_hinge = I(L.nb);
   L.i_hinge_body = I(L.nh); L.i_limited = I(L.nh); L.i_is_foot = I(L.nhum);
+  L.i_tree_limb = I(4 * 8); L.i_tree_trunk = I(10);
   for (int s = 0; s < 2; s++) {
     L.i_task_body[s] = I(L.K[s]); L.i_task_human[s] = I(L.K[s]);
     L.i_pair_task[s] = I(L.P[s]); L.i_pair_dof[s] = I(L.P[s]);
@@ -192,6 +263,13 @@ inline std::vector<char> make_ik_image(const gmr_model_t& m, const gmr_taskset_t
     sm[L.range_hi + i] = m.range_hi[i];
     si[L.i_hinge_body + i] = (short)m.hinge_body[i];
     si[L.i_limited + i] = (short)m.limited[i];
+  }
+  {
+    const IkTree tree = make_ik_tree(m);
+    for (int l = 0; l < 4; l++) for (int a2 = 0; a2 < 8; a2++) si[L.i_tree_limb + l * 8 + a2] = (short)tree.limb[l][a2];
+    for (int t2 = 0; t2 < 10; t2++) si[L.i_tree_trunk + t2] = (short)tree.trunk[t2];
+    reinterpret_cast<int*>(sw + L.w_tr_cnt)[1] = -1;
+    reinterpret_cast<int*>(sw + L.w_tr_cnt)[3] = -1;
   }
   for (int i = 0; i < L.nhum; i++) {
     sm[L.scale + i] = ts.scale[i];

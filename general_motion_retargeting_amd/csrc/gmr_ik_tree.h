@@ -1,0 +1,291 @@
+// gmr_ik_tree.h -- the box-QP of one IK solve, factorised along the kinematic tree by FOUR wavefronts.
+//
+// H = damping I + sum_k J_k^T W^2 J_k couples two dofs only if one is an ancestor of the other
+// (a task's Jacobian lives on its root->frame path).  Ordered limbs-first, H is block-arrowhead:
+//
+//        [ D_1            B_1^T ]      D_l : dofs of limb l (a chain: dense, <= 8)
+//    H = [      ...        ...  ]      T   : trunk dofs (floating base, waist, short appendages: <= 10)
+//        [            D_4 B_4^T ]      B_l : trunk x limb coupling
+//        [ B_1  ...  B_4   T    ]
+//
+// Each wavefront eliminates ONE limb (Cholesky of D_l, Y_l = B_l L_l^-T, its Schur contribution
+// -Y_l Y_l^T and the forward-substituted right-hand side) with its rows in registers exactly like the
+// dense solver, but on an 18-column local matrix: 108 instead of 630 (pivot, column) updates and 8
+// instead of 36 pivots on the critical path, the four limbs side by side.  The main wavefront then
+// factors the 10x10 trunk Schur complement, solves it, and the limbs back-substitute in parallel.
+// Bounds are handled by the same block principal pivoting as the dense solver (gmr_ik.hip); the bound
+// state of a variable lives in the lane that owns its row.  Five workgroup barriers per pivoting round.
+//
+// Used by the latency shape (NW = 4) when the robot decomposes into <= 4 limbs of <= 8 dofs and a
+// trunk of <= 10 (all 8 shipped robots do); otherwise the dense solver runs on the main wavefront.
+#pragma once
+
+namespace gmr {
+
+constexpr int TR_NL = 8;             // limb rows per wavefront
+constexpr int TR_NT = 10;            // trunk rows
+constexpr int TR_NV = TR_NL + TR_NT; // local matrix order
+constexpr int TR_LD = TR_NV + 1;     // row stride of the LDS transpose scratch
+
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo |= (unsigned)__shfl_xor((int)lo, off, 64);
+    hi |= (unsigned)__shfl_xor((int)hi, off, 64);
+  }
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// Bound sets of the QP, identical in every wavefront (wave-uniform registers, carried from solve to
+// solve for the warm start): bit d of `lower` / `upper` = dof d sits on its lower / upper bound.
+struct TreeState { unsigned long long lower, upper; };
+
+// All four wavefronts call this together.  Returns GMR_STATUS_* (the same value in every wavefront);
+// the solution is left in sm[L.x].  Three workgroup barriers per pivoting round (two when no bound is
+// active): the trunk system is summed, factorised and solved redundantly by every wavefront, so
+// the only exchanges are the limbs' Schur contributions, the solution x and the violation sets.
+__device__ __forceinline__ int solve_qp_tree(const IkLayout& L, double* sm, uint32_t* sw, const short* si, int wave,
+                                             int lane, TreeState& bs, Prof& pr) {
+  const int n = L.nv, ldh = L.ldh;
+  const double* H = sm + L.H;
+  const short* limb = si + L.i_tree_limb + wave * TR_NL;     // dof of limb row a, or -1
+  const short* trunk = si + L.i_tree_trunk;                  // dof of trunk row t, or -1
+  double* xs = sm + L.x;
+  const double* los = sm + L.lo;
+  const double* his = sm + L.hi;
+  double* Spart = sm + L.tr_spart;                           // [4][TR_NT][TR_NT]
+  double* rpart = sm + L.tr_rpart;                           // [4][TR_NT]
+  double* Lscr = sm + L.Kt + wave * TR_NV * TR_LD;           // this wavefront's transpose scratch
+  // violation sets of a round, double-buffered: {to_lower, to_upper, release, flags} x 2
+  unsigned long long* vset = reinterpret_cast<unsigned long long*>(sw + L.w_tr_mask);
+
+  const bool is_limb = lane < TR_NL, is_trunk = lane >= TR_NL && lane < TR_NV;
+  const int a = lane, t = lane - TR_NL;
+  const int dof = is_limb ? limb[a] : (is_trunk ? trunk[t] : -1);
+  const bool row = dof >= 0;                                 // this lane holds a real row
+  const bool own = row && (is_limb || wave == 0);            // ... and reports the variable's violations
+  const double lo = row ? los[dof] : 0.0, hi = row ? his[dof] : 0.0;
+  const double ci = row ? (sm + L.c)[dof] : 0.0;
+  const double* Hrow = H + (row ? dof : 0) * ldh;
+  double cabs = lane < n ? fabs((sm + L.c)[lane]) : 0.0;
+  const double dual_tol = 1e-13 * (1.0 + wave_max(cabs));
+  const double ptol_lo = 1e-12 * (1.0 + fabs(lo)), ptol_hi = 1e-12 * (1.0 + fabs(hi));
+  // column dofs of the local matrix (wave-uniform): limb columns then trunk columns
+  int cdof[TR_NV];
+#pragma unroll
+  for (int m = 0; m < TR_NL; m++) cdof[m] = limb[m];
+#pragma unroll
+  for (int u = 0; u < TR_NT; u++) cdof[TR_NL + u] = trunk[u];
+
+  int pcount = 3, ninf_best = 65;
+  for (int it = 0; it < 100; it++) {
+    PROF_BEGIN(pr);
+    const unsigned long long fixedm = bs.lower | bs.upper;
+    const bool self_fixed = !row || ((fixedm >> dof) & 1ull);
+    const double xfix = !row ? 0.0 : (((bs.lower >> dof) & 1ull) ? lo : (((bs.upper >> dof) & 1ull) ? hi : 0.0));
+    // ---- (1) local rows and right-hand side -----------------------------------------------------
+    double r[TR_NV];
+#pragma unroll
+    for (int m = 0; m < TR_NV; m++) r[m] = 0.0;
+#pragma unroll
+    for (int m = 0; m < TR_NL; m++) {
+      const int cd = cdof[m];                                 // wave-uniform
+      const bool cfixed = cd < 0 || ((fixedm >> cd) & 1ull);
+      // limb row a keeps columns m <= a; trunk rows keep all limb columns (B_l)
+      const bool keep = row && !self_fixed && !cfixed && (is_trunk || (is_limb && m <= a));
+      double h = (row && cd >= 0) ? Hrow[cd] : 0.0;
+      double v = keep ? h : 0.0;
+      if (is_limb && m == a && (self_fixed || cfixed)) v = 1.0;   // fixed / padding limb row: identity
+      r[m] = v;
+    }
+    // -c_i - sum over fixed j of H_ij x_j (the bound value of j from the uniform sets)
+    double rhs0 = row ? (self_fixed ? xfix : -ci) : 0.0;
+    if (row && !self_fixed) {
+      unsigned long long mm = fixedm;
+      while (mm) {
+        int j = __ffsll((long long)mm) - 1;
+        mm &= mm - 1;
+        rhs0 -= Hrow[j] * (((bs.lower >> j) & 1ull) ? los[j] : his[j]);
+      }
+    }
+    double b = is_limb ? rhs0 : 0.0;
+    PROF_END(pr, PH_KBUILD);
+    PROF_BEGIN(pr);
+    // ---- (2) eliminate the limb pivots (right-looking, forward substitution merged) --------------
+    double mydinv = 1.0;
+    bool bad = false;
+#pragma unroll
+    for (int p = 0; p < TR_NL; p++) {
+      const double dp = readlane_d(r[p], p);
+      bad = bad || !(dp > 0.0);
+      const double dinv = fast_rsqrt(dp);
+      double l = lane > p ? r[p] * dinv : 0.0;               // column p of L_l (rows > p) and of Y_l
+      if (lane == p) { mydinv = dinv; r[p] = dp * dinv; } else r[p] = l;
+      const double yp = readlane_d(b, p) * dinv;
+      b = lane == p ? yp : fma(-l, yp, b);
+#pragma unroll
+      for (int k0 = p + 1; k0 < TR_NV; k0 += 4) {
+        double lk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) lk[u] = (k0 + u < TR_NV) ? readlane_d(l, k0 + u) : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (k0 + u < TR_NV) r[k0 + u] = fma(-l, lk[u], r[k0 + u]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    PROF_END(pr, PH_CHOL);
+    PROF_BEGIN(pr);
+    // ---- (3) publish the Schur contribution; park L_l / Y_l for the transposed reads --------------
+    if (is_trunk) {
+#pragma unroll
+      for (int u = 0; u < TR_NT; u++) Spart[(wave * TR_NT + t) * TR_NT + u] = r[TR_NL + u];
+      rpart[wave * TR_NT + t] = b;
+    }
+    if (lane < TR_NV) {
+#pragma unroll
+      for (int m = 0; m < TR_NL; m++) Lscr[lane * TR_LD + m] = r[m];
+    }
+    unsigned long long* vcur = vset + 4 * (it & 1);
+    if (lane == 0 && bad) atomicOr(&vcur[3], 1ull);
+    __syncthreads();                                                                         // B1
+    // the other slot was last read before this barrier: clear it for the next round
+    if (wave == 0 && lane < 4) vset[4 * ((it + 1) & 1) + lane] = 0ull;
+    PROF_END(pr, PH_SUBST);
+    PROF_BEGIN(pr);
+    // ---- (4) every wavefront: trunk Schur complement, factor, solve (redundant, no exchange) -------
+    double bt = 0.0;
+    bool tbad = false;
+    {
+      double s[TR_NT];
+#pragma unroll
+      for (int u = 0; u < TR_NT; u++) s[u] = 0.0;
+      if (is_trunk) {
+#pragma unroll
+        for (int u = 0; u < TR_NT; u++) {
+          const int cd = cdof[TR_NL + u];
+          const bool cfixed = cd < 0 || ((fixedm >> cd) & 1ull);
+          double v = 0.0;
+          if (u <= t) {
+            if (row && !self_fixed && !cfixed) {
+              v = Hrow[cd];
+              v += (Spart[(0 * TR_NT + t) * TR_NT + u] + Spart[(1 * TR_NT + t) * TR_NT + u]) +
+                   (Spart[(2 * TR_NT + t) * TR_NT + u] + Spart[(3 * TR_NT + t) * TR_NT + u]);
+            } else if (u == t) v = 1.0;
+          }
+          s[u] = v;
+        }
+        bt = rhs0;
+        if (row && !self_fixed)
+          bt += (rpart[0 * TR_NT + t] + rpart[1 * TR_NT + t]) + (rpart[2 * TR_NT + t] + rpart[3 * TR_NT + t]);
+      }
+      double tdinv = 1.0;
+#pragma unroll
+      for (int q = 0; q < TR_NT; q++) {
+        const double dq = readlane_d(s[q], TR_NL + q);
+        tbad = tbad || !(dq > 0.0);
+        const double dinv = fast_rsqrt(dq);
+        double l = t > q ? s[q] * dinv : 0.0;
+        if (t == q) { tdinv = dinv; s[q] = dq * dinv; } else s[q] = l;
+        const double yq = readlane_d(bt, TR_NL + q) * dinv;
+        bt = t == q ? yq : fma(-l, yq, bt);
+        double lk[TR_NT];
+#pragma unroll
+        for (int k = q + 1; k < TR_NT; k++) lk[k] = readlane_d(l, TR_NL + k);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = q + 1; k < TR_NT; k++) s[k] = fma(-l, lk[k], s[k]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // back substitution: L^T through this wavefront's scratch (columns 8..17 of rows 8..17 are free)
+      double* Tscr = Lscr + TR_NL;
+      if (is_trunk) {
+#pragma unroll
+        for (int u = 0; u < TR_NT; u++) Tscr[lane * TR_LD + u] = s[u];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      double lt[TR_NT];
+#pragma unroll
+      for (int q = 0; q < TR_NT; q++) lt[q] = is_trunk ? Tscr[(TR_NL + q) * TR_LD + t] : 0.0;
+#pragma unroll
+      for (int q = TR_NT - 1; q >= 0; q--) {
+        const double xq = readlane_d(bt * tdinv, TR_NL + q);
+        bt = t == q ? xq : (is_trunk && t < q ? fma(-lt[q], xq, bt) : bt);
+      }
+    }
+    PROF_END(pr, PH_RATIO);
+    PROF_BEGIN(pr);
+    // ---- (5) limbs: y_l - Y_l^T x_T, then back substitution with L_l^T ----------------------------
+    double x = bt;                                                                     // trunk lanes
+    {
+      double lt[TR_NL];
+#pragma unroll
+      for (int m = 0; m < TR_NL; m++) lt[m] = is_limb ? Lscr[m * TR_LD + a] : 0.0;     // column a of L_l
+      double bb = b;                                                                   // y_l (limb lanes)
+#pragma unroll
+      for (int u = 0; u < TR_NT; u++) {
+        const double xt = readlane_d(bt, TR_NL + u);
+        if (is_limb) bb = fma(-Lscr[(TR_NL + u) * TR_LD + a], xt, bb);                 // Y_l[u][a]
+      }
+#pragma unroll
+      for (int p = TR_NL - 1; p >= 0; p--) {
+        const double xp = readlane_d(bb * mydinv, p);
+        bb = lane == p ? xp : (lane < p ? fma(-lt[p], xp, bb) : bb);
+      }
+      if (is_limb) x = bb;
+    }
+    // ---- (6) violated bounds (free set) / multipliers (fixed set): g = H x + c ---------------------
+    if (fixedm != 0ull) {                                     // multipliers need the whole x
+      if (own) xs[dof] = x;
+      __syncthreads();                                                                       // B2
+    }
+    PROF_END(pr, PH_MULT);
+    PROF_BEGIN(pr);
+    int newst = 0;                                            // 0 none, 1 -> lower, 2 -> upper, 3 release
+    if (own) {
+      if (!self_fixed) {
+        if (x < lo - ptol_lo) newst = 1;
+        else if (x > hi + ptol_hi) newst = 2;
+      } else {
+        double g0 = ci, g1 = 0.0;
+        int j = 0;
+        for (; j + 1 < n; j += 2) { g0 = fma(Hrow[j], xs[j], g0); g1 = fma(Hrow[j + 1], xs[j + 1], g1); }
+        if (j < n) g0 = fma(Hrow[j], xs[j], g0);
+        const double g = g0 + g1;
+        const bool at_lower = (bs.lower >> dof) & 1ull;
+        if (at_lower ? g < -dual_tol : g > dual_tol) newst = 3;
+      }
+    }
+    const unsigned long long bit = row ? (1ull << dof) : 0ull;
+    unsigned long long m1 = wave_or64(newst == 1 ? bit : 0ull), m2 = wave_or64(newst == 2 ? bit : 0ull),
+                       m3 = wave_or64(newst == 3 ? bit : 0ull);
+    if (lane == 0) {
+      if (m1) atomicOr(&vcur[0], m1);
+      if (m2) atomicOr(&vcur[1], m2);
+      if (m3) atomicOr(&vcur[2], m3);
+      if (tbad) atomicOr(&vcur[3], 1ull);
+    }
+    __syncthreads();                                                                         // B3
+    PROF_END(pr, PH_IO);
+    const unsigned long long to_lo = vcur[0], to_up = vcur[1], rel = vcur[2];
+    if (vcur[3]) return GMR_STATUS_QP_FAILED;
+    const unsigned long long all = to_lo | to_up | rel;
+    if (all == 0ull) {
+      if (own) xs[dof] = fmin(fmax(x, lo), hi);
+      __syncthreads();
+      return GMR_STATUS_OK;
+    }
+    const int total = __popcll(all);
+    unsigned long long sel = all;                             // block principal pivoting: exchange all
+    if (total < ninf_best) { ninf_best = total; pcount = 3; }
+    else if (pcount > 0) pcount--;
+    else sel = 1ull << (63 - __clzll((long long)all));        // Murty: only the highest violated variable
+    bs.lower = (bs.lower & ~(rel & sel)) | (to_lo & sel);
+    bs.upper = (bs.upper & ~(rel & sel)) | (to_up & sel);
+  }
+  return GMR_STATUS_QP_MAXITER;
+}
+
+}  // namespace gmr
