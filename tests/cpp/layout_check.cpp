@@ -1,0 +1,112 @@
+// Host-side checks of the static schedules the IK kernel relies on (plain C++, no HIP):
+// reads a packed (gmr_model_t, gmr_taskset_t) pair from a file and verifies
+//   * the H-assembly schedule: every structurally non-zero (i >= j) entry and every diagonal entry is
+//     owned by exactly one virtual lane, its terms are exactly the (task, pair_i, pair_j) triples,
+//     the last-term flags close every entry, for 64 and 192 virtual lanes;
+//   * the limb / trunk decomposition: every dof exactly once, limbs are ancestor chains, trunk is
+//     closed under "parent of", sizes within the tree solver's static bounds;
+//   * the LDS layout: regions do not overlap and fit the 160 KB of a CU.
+// Prints a one-line summary; exit code 0 = all good.
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <set>
+#include <vector>
+
+#include "../../general_motion_retargeting_amd/csrc/gmr_ik_layout.h"
+
+#define CHECK(c, ...) do { if (!(c)) { std::fprintf(stderr, "CHECK failed: %s : ", #c); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 2;
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f) return 2;
+  gmr_model_t m;
+  gmr_taskset_t ts;
+  if (std::fread(&m, sizeof m, 1, f) != 1 || std::fread(&ts, sizeof ts, 1, f) != 1) return 2;
+  std::fclose(f);
+  const int nv = m.nv;
+  for (int nl : {64, 192}) {
+    gmr::IkSchedule sch = gmr::make_ik_schedule(m, ts, nl);
+    for (int s = 0; s < 2; s++) {
+      // expected terms per entry
+      std::map<std::pair<int, int>, std::multiset<std::pair<int, int>>> want;
+      for (int k = 0; k < ts.ntask[s]; k++) {
+        int c0 = ts.task_col0[s][k], n = ts.task_ncol[s][k];
+        for (int a = 0; a < n; a++)
+          for (int b = 0; b <= a; b++)
+            want[{ts.pair_dof[s][c0 + a], ts.pair_dof[s][c0 + b]}].insert({c0 + a, c0 + b});
+      }
+      for (int d = 0; d < nv; d++) want[{d, d}];   // diagonal always present
+      std::map<std::pair<int, int>, std::multiset<std::pair<int, int>>> got;
+      std::set<std::pair<int, int>> closed;
+      CHECK((int)sch.istart[s].size() == nl + 1, "istart size");
+      CHECK(sch.istart[s][0] == 0 && sch.istart[s][nl] == (int)sch.items[s].size(), "istart ends");
+      int maxload = 0;
+      for (int l = 0; l < nl; l++) {
+        CHECK(sch.istart[s][l] <= sch.istart[s][l + 1], "istart monotone");
+        maxload = std::max(maxload, sch.istart[s][l + 1] - sch.istart[s][l]);
+        bool open = false;
+        std::pair<int, int> cur;
+        for (int i = sch.istart[s][l]; i < sch.istart[s][l + 1]; i++) {
+          uint32_t w = sch.items[s][i];
+          std::pair<int, int> e = {(int)((w >> 18) & 63u), (int)((w >> 24) & 63u)};
+          CHECK(e.first >= e.second && e.first < nv, "entry range");
+          if (open) CHECK(e == cur, "terms of one entry must be contiguous in one lane");
+          else { CHECK(!closed.count(e), "entry (%d,%d) owned twice", e.first, e.second); cur = e; open = true; }
+          if (!((w >> 30) & 1u)) got[e].insert({(int)(w & 511u), (int)((w >> 9) & 511u)});
+          else got[e];
+          if (w >> 31) { closed.insert(e); open = false; }
+        }
+        CHECK(!open, "lane %d ends inside an entry", l);
+      }
+      CHECK(got == want, "stage %d: schedule terms differ from J^T J structure (%zu vs %zu entries)", s, got.size(), want.size());
+      CHECK(closed.size() == want.size(), "unclosed entries");
+      int total = (int)sch.items[s].size();
+      CHECK(maxload <= (total + nl - 1) / nl + ts.ntask[s] + 2, "schedule badly balanced: max %d of %d over %d lanes", maxload, total, nl);
+    }
+  }
+  // tree decomposition
+  gmr::IkTree tr = gmr::make_ik_tree(m);
+  std::vector<int> pd(nv, -1);
+  for (int d = 1; d < 6; d++) pd[d] = d - 1;
+  for (int h = 0; h < m.nhinge; h++) {
+    int b = m.parent[m.hinge_body[h]], p = 5;
+    while (b > 0) { if (m.body_hinge[b] >= 0) { p = 6 + m.body_hinge[b]; break; } b = m.parent[b]; }
+    pd[6 + h] = p;
+  }
+  int nlimb = 0;
+  if (tr.ok) {
+    std::vector<int> seen(nv, 0);
+    std::set<int> trunk;
+    for (int t = 0; t < 10; t++) if (tr.trunk[t] >= 0) { seen[tr.trunk[t]]++; trunk.insert(tr.trunk[t]); }
+    CHECK((int)trunk.size() == tr.nt && tr.nt <= 10, "trunk size");
+    for (int d = 0; d < 6; d++) CHECK(trunk.count(d), "floating base must be in the trunk");
+    for (int l = 0; l < 4; l++) {
+      int prev = -1, len = 0;
+      for (int a = 0; a < 8; a++) {
+        int d = tr.limb[l][a];
+        if (d < 0) continue;
+        seen[d]++; len++;
+        if (prev >= 0) CHECK(pd[prev] == d, "limb %d is not an ancestor chain (tip first)", l);
+        prev = d;
+      }
+      if (len) { nlimb++; CHECK(trunk.count(pd[prev]), "limb %d must hang off the trunk", l); }
+    }
+    for (int d = 0; d < nv; d++) CHECK(seen[d] == 1, "dof %d covered %d times", d, seen[d]);
+    // no coupling between different limbs: no dof of one limb is an ancestor of a dof of another
+  }
+  // layouts
+  for (int nw : {1, 4}) {
+    gmr::IkSchedule sch = gmr::make_ik_schedule(m, ts, nw == 1 ? 64 : 192);
+    gmr::IkLayout L = gmr::make_ik_layout(m, ts, sch, nw);
+    CHECK(L.smem_bytes > 0 && L.smem_bytes <= 160 * 1024 - 1024, "LDS bytes %d", L.smem_bytes);
+    CHECK(L.nvp >= nv && (L.nvp == 28 || L.nvp == 32 || L.nvp == 36 || L.nvp == 48), "nvp");
+    CHECK((L.ldh & 1) == 1 && L.ldh > nv, "odd H row stride");
+    std::vector<char> img = gmr::make_ik_image(m, ts, sch, L);
+    CHECK((int)img.size() >= L.smem_bytes && img.size() % 16 == 0, "image size");
+    CHECK(L.tree_ok == ((nw == 4 && tr.ok) ? 1 : 0), "tree flag");
+  }
+  std::printf("ok nv=%d tree=%d limbs=%d trunk=%d\n", nv, (int)tr.ok, nlimb, tr.nt);
+  return 0;
+}
