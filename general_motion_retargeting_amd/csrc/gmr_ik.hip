@@ -191,7 +191,7 @@ __device__ __forceinline__ double errors_wave(const IkLayout& L, double* sm, con
 // ---------------------------------------------------------------------------------------------
 struct StageTabs {
   const short* task_body; const short* task_human; const short* pair_task; const short* pair_dof;
-  const short* pair_index; const uint32_t* items; const int* istart;
+  const short* pair_index; const uint32_t* items;
 };
 
 // (a) lane = task: M_k = -Jl^-1(e_k) (blocks -A, -B), weighted residual; returns the LM term mu
@@ -306,30 +306,29 @@ __device__ __forceinline__ void cvec_phase(const IkLayout& L, double* sm, int st
 }
 
 // (d) H: every (virtual) lane sums the terms of the entries it owns (static schedule) and stores each
-// once.  Two terms per trip, operands of both loaded before any store (Jw read-only, H write-only).
-__device__ __forceinline__ void hacc_phase(const IkLayout& L, double* sm, const StageTabs& tb, double diag,
+// once.  The schedule is padded to a wave-uniform number of slots and stored [slot][lane]; two terms per
+// trip, operands of both loaded (as 16-B pieces) before any store (Jw read-only, H write-only).
+struct dd2 { double x, y; };
+__device__ __forceinline__ double dot6v(const double* a, const double* b) {
+  const dd2* pa = reinterpret_cast<const dd2*>(a);
+  const dd2* pb = reinterpret_cast<const dd2*>(b);
+  dd2 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+  return (a0.x * b0.x + a0.y * b0.y + a1.x * b1.x) + (a1.y * b1.y + a2.x * b2.x + a2.y * b2.y);
+}
+
+__device__ __forceinline__ void hacc_phase(const IkLayout& L, double* sm, int stage, const StageTabs& tb, double diag,
                                            int vlane) {
-  const int ldh = L.ldh;
+  const int ldh = L.ldh, nl = L.nlanes, ntrip = L.ntrip[stage];
   double* __restrict__ H = sm + L.H;
   const double* __restrict__ J = sm + L.Jw;
-  const uint32_t* items = tb.items;
-  const int i1 = tb.istart[vlane + 1];
-  int it = tb.istart[vlane];
+  const uint32_t* items = tb.items + vlane;
   double acc = 0.0;
-  uint32_t n0 = it < i1 ? items[it] : 0u, n1 = it + 1 < i1 ? items[it + 1] : 0u;
-  for (; it + 1 < i1; it += 2) {
+  uint32_t n0 = items[0], n1 = items[nl];
+  for (int it = 0; it < ntrip; it += 2) {
     const uint32_t w0 = n0, w1 = n1;
-    n0 = it + 2 < i1 ? items[it + 2] : 0u;   // next trip's item words are in flight during this one
-    n1 = it + 3 < i1 ? items[it + 3] : 0u;
-    const double* a0 = J + 6 * (w0 & 511u);
-    const double* b0 = J + 6 * ((w0 >> 9) & 511u);
-    const double* a1 = J + 6 * (w1 & 511u);
-    const double* b1 = J + 6 * ((w1 >> 9) & 511u);
-    double x0[6], y0[6], x1[6], y1[6];
-#pragma unroll
-    for (int r = 0; r < 6; r++) { x0[r] = a0[r]; y0[r] = b0[r]; x1[r] = a1[r]; y1[r] = b1[r]; }
-    double s0 = (x0[0] * y0[0] + x0[1] * y0[1] + x0[2] * y0[2]) + (x0[3] * y0[3] + x0[4] * y0[4] + x0[5] * y0[5]);
-    double s1 = (x1[0] * y1[0] + x1[1] * y1[1] + x1[2] * y1[2]) + (x1[3] * y1[3] + x1[4] * y1[4] + x1[5] * y1[5]);
+    if (it + 2 < ntrip) { n0 = items[(it + 2) * nl]; n1 = items[(it + 3) * nl]; }   // next trip in flight
+    double s0 = dot6v(J + 6 * (w0 & 511u), J + 6 * ((w0 >> 9) & 511u));
+    double s1 = dot6v(J + 6 * (w1 & 511u), J + 6 * ((w1 >> 9) & 511u));
     if ((w0 >> 30) & 1u) s0 = 0.0;
     if ((w1 >> 30) & 1u) s1 = 0.0;
     acc += s0;
@@ -347,17 +346,6 @@ __device__ __forceinline__ void hacc_phase(const IkLayout& L, double* sm, const 
       H[da * ldh + db] = v;
       H[db * ldh + da] = v;
       acc = 0.0;
-    }
-  }
-  if (it < i1) {
-    const uint32_t w0 = n0;
-    double s0 = ((w0 >> 30) & 1u) ? 0.0 : dot6(J + 6 * (w0 & 511u), J + 6 * ((w0 >> 9) & 511u));
-    acc += s0;
-    if (w0 >> 31) {
-      int da = (w0 >> 18) & 63u, db = (w0 >> 24) & 63u;
-      double v = acc + (da == db ? diag : 0.0);
-      H[da * ldh + db] = v;
-      H[db * ldh + da] = v;
     }
   }
 }
@@ -381,7 +369,7 @@ __device__ __forceinline__ void build_qp_main(const IkLayout& L, double* sm, int
     cvec_phase(L, sm, stage, tb, limited, limit_gain, lane);
     PROF_END(pr, PH_CVEC);
     PROF_BEGIN(pr);
-    hacc_phase(L, sm, tb, diag, lane);
+    hacc_phase(L, sm, stage, tb, diag, lane);
     WSYNC();
     PROF_END(pr, PH_HACC);
   } else {
@@ -403,22 +391,32 @@ __device__ __forceinline__ void build_qp_main(const IkLayout& L, double* sm, int
 // helper waves (NW > 1): serve assembly requests until the main wave says EXIT
 template <int NW>
 __device__ __forceinline__ void helper_loop(const IkLayout& L, double* sm, const uint32_t* sw, const short* si,
-                                            const short* hinge_body, const int* ctl, int wave, int lane) {
+                                            const short* hinge_body, const int* ctl, int wave, int lane,
+                                            Prof& hp) {
   TreeState bs = {0ull, 0ull};            // bound sets of the QP (identical in every wavefront)
   for (;;) {
+    PROF_BEGIN(hp);
     __syncthreads();                      // B1 (or the EXIT barrier)
+    PROF_END(hp, PH_PRE);                 // (helper stamps reuse the slots: PRE = idle at B1)
     const int cmd = ctl[0];
     if (cmd == CMD_EXIT) return;
     const int stage = ctl[1];
     const double diag = (sm + L.scal)[0];
     StageTabs tb = {si + L.i_task_body[stage], si + L.i_task_human[stage], si + L.i_pair_task[stage],
-                    si + L.i_pair_dof[stage], si + L.i_pair_index[stage], sw + L.w_items[stage],
-                    reinterpret_cast<const int*>(sw + L.w_istart[stage])};
+                    si + L.i_pair_dof[stage], si + L.i_pair_index[stage], sw + L.w_items[stage]};
+    PROF_BEGIN(hp);
     pairs_phase(L, sm, stage, tb, hinge_body, wave * 64 + lane, 64 * NW);
+    PROF_END(hp, PH_PAIRS);
+    PROF_BEGIN(hp);
     __syncthreads();                      // B2
-    hacc_phase(L, sm, tb, diag, (wave - 1) * 64 + lane);
+    PROF_END(hp, PH_CVEC);                // wait at B2
+    PROF_BEGIN(hp);
+    hacc_phase(L, sm, stage, tb, diag, (wave - 1) * 64 + lane);
+    PROF_END(hp, PH_HACC);
+    PROF_BEGIN(hp);
     __syncthreads();                      // B3
-    if (L.tree_ok) { Prof hp; (void)solve_qp_tree(L, sm, const_cast<uint32_t*>(sw), si, wave, lane, bs, hp); }
+    PROF_END(hp, PH_JLOG);                // wait at B3
+    if (L.tree_ok) (void)solve_qp_tree(L, sm, const_cast<uint32_t*>(sw), si, wave, lane, bs, hp);
   }
 }
 
@@ -679,7 +677,11 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
   }
   __syncthreads();
   if (NW > 1 && wave > 0) {
-    helper_loop<NW>(L, sm, sw, si, hinge_body, ctl, wave, lane);
+    helper_loop<NW>(L, sm, sw, si, hinge_body, ctl, wave, lane, pr);
+#ifdef GMR_IK_PROFILE
+    if (wave == 1 && lane == 0 && prof_out)      // second row of stamps: helper wavefront 1
+      for (int i = 0; i < PH_COUNT; i++) prof_out[((size_t)S + s) * PH_COUNT + i] = pr.acc[i];
+#endif
     return;
   }
   const double damping = P.damping, lm_damping = P.lm_damping, tol = P.tol, limit_gain = P.limit_gain;
@@ -720,8 +722,7 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
       for (int stage = 0; stage < 2; stage++) {
         if (!(stage == 0 ? use0 : use1)) continue;
         const StageTabs tb = {si + L.i_task_body[stage], si + L.i_task_human[stage], si + L.i_pair_task[stage],
-                              si + L.i_pair_dof[stage], si + L.i_pair_index[stage], sw + L.w_items[stage],
-                              reinterpret_cast<const int*>(sw + L.w_istart[stage])};
+                              si + L.i_pair_dof[stage], si + L.i_pair_index[stage], sw + L.w_items[stage]};
         const int K = L.K[stage];
         if (h_stage != stage) {
           // structural zeros of H are never written by the schedule: clear when the pattern changes

@@ -17,7 +17,7 @@ struct IkLayout {
   // dimensions
   int nb, nh, nq, nv, nvp, nw, nhum, maxd, nhop, ldh;
   int tree_ok, tree_nt;          // limb/trunk decomposition usable by the 4-wavefront tree solver
-  int K[2], P[2], nitem[2];
+  int K[2], P[2], nitem[2], ntrip[2], nlanes;
   // offsets in doubles
   int body_pos, body_quat, axis, range_lo, range_hi, scale, pos_off, quat_off;
   int wpos[2], wrot[2];
@@ -55,7 +55,13 @@ struct IkSchedule {
   int nlanes;                      // virtual lanes that share the assembly: 64 (one wave) or 192 (3 helpers)
   std::vector<uint32_t> items[2];
   std::vector<int> istart[2];      // nlanes + 1 offsets
+  // what the kernel reads: every lane padded to ntrip slots with no-op words, stored [slot][lane] so that
+  // a wave reads consecutive words (conflict-free) and the loop trip count is wave-uniform
+  int ntrip[2];
+  std::vector<uint32_t> padded[2];
 };
+
+constexpr uint32_t IK_ITEM_NOP = 1u << 30;   // contributes nothing, closes nothing
 
 inline IkSchedule make_ik_schedule(const gmr_model_t& m, const gmr_taskset_t& ts, int nlanes) {
   IkSchedule sch;
@@ -100,6 +106,14 @@ inline IkSchedule make_ik_schedule(const gmr_model_t& m, const gmr_taskset_t& ts
       }
     }
     sch.istart[s][nlanes] = (int)sch.items[s].size();
+    int nt = 0;
+    for (int l = 0; l < nlanes; l++) nt = std::max(nt, sch.istart[s][l + 1] - sch.istart[s][l]);
+    nt = (nt + 1) & ~1;                       // two slots per loop trip
+    sch.ntrip[s] = nt;
+    sch.padded[s].assign((size_t)nt * nlanes, IK_ITEM_NOP);
+    for (int l = 0; l < nlanes; l++)
+      for (int i = sch.istart[s][l]; i < sch.istart[s][l + 1]; i++)
+        sch.padded[s][(size_t)(i - sch.istart[s][l]) * nlanes + l] = sch.items[s][i];
   }
   return sch;
 }
@@ -181,7 +195,8 @@ inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, co
   L.nhop = 0;
   while ((1 << L.nhop) < maxd) L.nhop++;
   L.ldh = (m.nv % 2 == 0) ? m.nv + 1 : m.nv + 2;  // odd row stride (in doubles): conflict-free column reads
-  for (int s = 0; s < 2; s++) { L.K[s] = ts.ntask[s]; L.P[s] = ts.npair[s]; L.nitem[s] = (int)sch.items[s].size(); }
+  for (int s = 0; s < 2; s++) { L.K[s] = ts.ntask[s]; L.P[s] = ts.npair[s]; L.nitem[s] = (int)sch.padded[s].size(); L.ntrip[s] = sch.ntrip[s]; }
+  L.nlanes = sch.nlanes;
   int Kmax = std::max(L.K[0], L.K[1]);
   int Pmax = std::max(L.P[0], L.P[1]);
   int o = 0;
@@ -194,7 +209,9 @@ inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, co
   L.xa = D(7 * L.nb + 1); L.xb = D(7 * L.nb + 1);   // ping-pong (pos, quat) of the FK rounds
   L.xaxis = D(3 * L.nb);
   L.raw = D(7 * L.nhum + 1); L.tgt = D(7 * L.nhum + 1);
-  L.e = D(6 * Kmax); L.eaux = D(3 * Kmax); L.we = D(6 * Kmax); L.M = D(18 * Kmax); L.Jw = D(6 * Pmax); L.cpart = D(Pmax);
+  L.e = D(6 * Kmax); L.eaux = D(3 * Kmax); L.we = D(6 * Kmax); L.M = D(18 * Kmax);
+  if (o & 1) o++;                             // Jw rows (48 B) are read as three 16-B pieces
+  L.Jw = D(6 * Pmax); L.cpart = D(Pmax);
   L.H = D(L.nv * L.ldh + 2);
   L.Kt = D(std::max(L.nvp * (L.nvp + 1), nw == 4 ? 4 * 18 * 19 : 0));   // dense transpose / 4 tree-solver scratches
   L.c = D(L.nv); L.x = D(L.nv); L.lo = D(L.nv); L.hi = D(L.nv); L.scal = D(2);
@@ -202,7 +219,7 @@ inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, co
   L.n_double = o;
   int w = 0;
   auto W = [&](int n) { int r = w; w += n; return r; };
-  for (int s = 0; s < 2; s++) { L.w_items[s] = W(L.nitem[s]); L.w_istart[s] = W(sch.nlanes + 1); }
+  for (int s = 0; s < 2; s++) { L.w_items[s] = W(L.nitem[s]); L.w_istart[s] = 0; }
   L.w_ctl = W(2);
   if (w % 2) w++;
   L.w_tr_mask = W(16); L.w_tr_cnt = W(4);
@@ -278,8 +295,7 @@ inline std::vector<char> make_ik_image(const gmr_model_t& m, const gmr_taskset_t
     si[L.i_is_foot + i] = (short)ts.is_foot[i];
   }
   for (int s = 0; s < 2; s++) {
-    for (size_t i = 0; i < sch.items[s].size(); i++) sw[L.w_items[s] + i] = sch.items[s][i];
-    for (int l = 0; l <= sch.nlanes; l++) sw[L.w_istart[s] + l] = (uint32_t)sch.istart[s][l];
+    for (size_t i = 0; i < sch.padded[s].size(); i++) sw[L.w_items[s] + i] = sch.padded[s][i];
     for (int k = 0; k < L.K[s]; k++) {
       si[L.i_task_body[s] + k] = (short)ts.task_body[s][k];
       si[L.i_task_human[s] + k] = (short)ts.task_human[s][k];

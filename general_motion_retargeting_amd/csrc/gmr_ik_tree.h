@@ -113,28 +113,28 @@ __device__ __forceinline__ int solve_qp_tree(const IkLayout& L, double* sm, uint
     PROF_END(pr, PH_KBUILD);
     PROF_BEGIN(pr);
     // ---- (2) eliminate the limb pivots (right-looking, forward substitution merged) --------------
+    // The next pivot's column is updated first and its reciprocal square root started at once, so
+    // that the Newton steps overlap the remaining (independent) column updates of this pivot.
     double mydinv = 1.0;
     bool bad = false;
+    double dp = readlane_d(r[0], 0);
+    double dinv = fast_rsqrt(dp);
 #pragma unroll
     for (int p = 0; p < TR_NL; p++) {
-      const double dp = readlane_d(r[p], p);
       bad = bad || !(dp > 0.0);
-      const double dinv = fast_rsqrt(dp);
       double l = lane > p ? r[p] * dinv : 0.0;               // column p of L_l (rows > p) and of Y_l
       if (lane == p) { mydinv = dinv; r[p] = dp * dinv; } else r[p] = l;
+      double dinv_next = 1.0;
+      if (p + 1 < TR_NL) {
+        r[p + 1] = fma(-l, readlane_d(l, p + 1), r[p + 1]);
+        dp = readlane_d(r[p + 1], p + 1);
+        dinv_next = fast_rsqrt(dp);
+      }
       const double yp = readlane_d(b, p) * dinv;
       b = lane == p ? yp : fma(-l, yp, b);
 #pragma unroll
-      for (int k0 = p + 1; k0 < TR_NV; k0 += 4) {
-        double lk[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) lk[u] = (k0 + u < TR_NV) ? readlane_d(l, k0 + u) : 0.0;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (k0 + u < TR_NV) r[k0 + u] = fma(-l, lk[u], r[k0 + u]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      for (int k = (p + 1 < TR_NL ? p + 2 : p + 1); k < TR_NV; k++) r[k] = fma(-l, readlane_d(l, k), r[k]);
+      dinv = dinv_next;
     }
     PROF_END(pr, PH_CHOL);
     PROF_BEGIN(pr);
@@ -162,42 +162,48 @@ __device__ __forceinline__ int solve_qp_tree(const IkLayout& L, double* sm, uint
       double s[TR_NT];
 #pragma unroll
       for (int u = 0; u < TR_NT; u++) s[u] = 0.0;
-      if (is_trunk) {
+      {
+        // all loads first (clamped addresses, no branches), then the masks
+        const int tt = is_trunk ? t : 0;
+        double hv[TR_NT], sp[TR_NT];
 #pragma unroll
         for (int u = 0; u < TR_NT; u++) {
           const int cd = cdof[TR_NL + u];
-          const bool cfixed = cd < 0 || ((fixedm >> cd) & 1ull);
-          double v = 0.0;
-          if (u <= t) {
-            if (row && !self_fixed && !cfixed) {
-              v = Hrow[cd];
-              v += (Spart[(0 * TR_NT + t) * TR_NT + u] + Spart[(1 * TR_NT + t) * TR_NT + u]) +
-                   (Spart[(2 * TR_NT + t) * TR_NT + u] + Spart[(3 * TR_NT + t) * TR_NT + u]);
-            } else if (u == t) v = 1.0;
-          }
+          hv[u] = Hrow[cd >= 0 ? cd : 0];
+          const double* q0 = Spart + tt * TR_NT + u;
+          sp[u] = (q0[0] + q0[TR_NT * TR_NT]) + (q0[2 * TR_NT * TR_NT] + q0[3 * TR_NT * TR_NT]);
+        }
+        const double rp = (rpart[tt] + rpart[TR_NT + tt]) + (rpart[2 * TR_NT + tt] + rpart[3 * TR_NT + tt]);
+        const bool live = is_trunk && row && !self_fixed;
+#pragma unroll
+        for (int u = 0; u < TR_NT; u++) {
+          const int cd = cdof[TR_NL + u];
+          const bool cfixed = cd < 0 || ((fixedm >> cd) & 1ull);           // wave-uniform
+          double v = (live && !cfixed && u <= t) ? hv[u] + sp[u] : 0.0;
+          if (is_trunk && u == t && !(live && !cfixed)) v = 1.0;
           s[u] = v;
         }
-        bt = rhs0;
-        if (row && !self_fixed)
-          bt += (rpart[0 * TR_NT + t] + rpart[1 * TR_NT + t]) + (rpart[2 * TR_NT + t] + rpart[3 * TR_NT + t]);
+        bt = is_trunk ? (live ? rhs0 + rp : rhs0) : 0.0;
       }
       double tdinv = 1.0;
+      double dq = readlane_d(s[0], TR_NL);
+      double dinv = fast_rsqrt(dq);
 #pragma unroll
       for (int q = 0; q < TR_NT; q++) {
-        const double dq = readlane_d(s[q], TR_NL + q);
         tbad = tbad || !(dq > 0.0);
-        const double dinv = fast_rsqrt(dq);
         double l = t > q ? s[q] * dinv : 0.0;
         if (t == q) { tdinv = dinv; s[q] = dq * dinv; } else s[q] = l;
+        double dinv_next = 1.0;
+        if (q + 1 < TR_NT) {
+          s[q + 1] = fma(-l, readlane_d(l, TR_NL + q + 1), s[q + 1]);
+          dq = readlane_d(s[q + 1], TR_NL + q + 1);
+          dinv_next = fast_rsqrt(dq);
+        }
         const double yq = readlane_d(bt, TR_NL + q) * dinv;
         bt = t == q ? yq : fma(-l, yq, bt);
-        double lk[TR_NT];
 #pragma unroll
-        for (int k = q + 1; k < TR_NT; k++) lk[k] = readlane_d(l, TR_NL + k);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = q + 1; k < TR_NT; k++) s[k] = fma(-l, lk[k], s[k]);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int k = q + 2; k < TR_NT; k++) s[k] = fma(-l, readlane_d(l, TR_NL + k), s[k]);
+        dinv = dinv_next;
       }
       // back substitution: L^T through this wavefront's scratch (columns 8..17 of rows 8..17 are free)
       double* Tscr = Lscr + TR_NL;
@@ -258,15 +264,9 @@ __device__ __forceinline__ int solve_qp_tree(const IkLayout& L, double* sm, uint
         if (at_lower ? g < -dual_tol : g > dual_tol) newst = 3;
       }
     }
-    const unsigned long long bit = row ? (1ull << dof) : 0ull;
-    unsigned long long m1 = wave_or64(newst == 1 ? bit : 0ull), m2 = wave_or64(newst == 2 ? bit : 0ull),
-                       m3 = wave_or64(newst == 3 ? bit : 0ull);
-    if (lane == 0) {
-      if (m1) atomicOr(&vcur[0], m1);
-      if (m2) atomicOr(&vcur[1], m2);
-      if (m3) atomicOr(&vcur[2], m3);
-      if (tbad) atomicOr(&vcur[3], 1ull);
-    }
+    // each violating owner lane sets its dof's bit in the round's set (LDS atomic OR: order-independent)
+    if (newst != 0) atomicOr(&vcur[newst - 1], 1ull << dof);
+    if (lane == 0 && tbad) atomicOr(&vcur[3], 1ull);
     __syncthreads();                                                                         // B3
     PROF_END(pr, PH_IO);
     const unsigned long long to_lo = vcur[0], to_up = vcur[1], rel = vcur[2];

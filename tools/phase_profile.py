@@ -41,14 +41,16 @@ def main():
     d_qo = _lib.DeviceBuffer(S * T * sol.nq * 8)
     d_ns = _lib.DeviceBuffer(S * T * 8)
     d_st = _lib.DeviceBuffer(S * 4)
-    d_pr = _lib.DeviceBuffer(S * len(PH) * 8)
+    d_pr = _lib.DeviceBuffer(2 * S * len(PH) * 8)
+    _lib.check(L.gmr_memset(d_pr.ptr, 0, 2 * S * len(PH) * 8, None))
     fn = L.gmr_retarget_streams_prof
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 4
     for _ in range(2):
         _lib.check(fn(sol.handle, S, T, d_q0.ptr, d_h.ptr, 0, d_qo.ptr, d_ns.ptr, d_st.ptr, d_pr.ptr))
     _lib.check(L.gmr_stream_sync(None))
-    pr = d_pr.to_host((S, len(PH)), np.uint64).astype(np.float64)
+    both = d_pr.to_host((2, S, len(PH)), np.uint64).astype(np.float64)
+    pr, hp = both[0], both[1]
     tot = pr[:, :14].sum(axis=1).mean()
     nsolve = pr[:, 15].mean()
     nfact = pr[:, 14].mean()
@@ -62,6 +64,10 @@ def main():
         rt.min(), np.median(rt), rt.max(), (pr[:, 14] / pr[:, 15]).min(), (pr[:, 14] / pr[:, 15]).max()))
     for i, n in enumerate(PH[:14]):
         print(f"  {n:7s} {pr[:, i].mean() / tot * 100:6.2f} %   {pr[:, i].mean() / nsolve:10.0f} /solve")
+    if hp.sum() > 0:
+        print("  helper wavefront 1 (cycles/solve): idle at B1 %.0f, Jacobian share %.0f, wait B2 %.0f, H share %.0f, wait B3 %.0f, tree-QP %.0f" % (
+            hp[:, 0].mean() / nsolve, hp[:, 4].mean() / nsolve, hp[:, 5].mean() / nsolve, hp[:, 6].mean() / nsolve,
+            hp[:, 3].mean() / nsolve, hp[:, 7:14].sum(axis=1).mean() / nsolve))
 
 
 if __name__ == "__main__":
