@@ -319,6 +319,7 @@ __device__ __forceinline__ double dot6v(const double* a, const double* b) {
 __device__ __forceinline__ void hacc_phase(const IkLayout& L, double* sm, int stage, const StageTabs& tb, double diag,
                                            int vlane) {
   const int ldh = L.ldh, nl = L.nlanes, ntrip = L.ntrip[stage];
+  const bool paired = vlane < L.pair_lanes;       // the whole first helper wavefront, or nobody
   double* __restrict__ H = sm + L.H;
   const double* __restrict__ J = sm + L.Jw;
   const uint32_t* items = tb.items + vlane;
@@ -332,7 +333,18 @@ __device__ __forceinline__ void hacc_phase(const IkLayout& L, double* sm, int st
     if ((w0 >> 30) & 1u) s0 = 0.0;
     if ((w1 >> 30) & 1u) s1 = 0.0;
     acc += s0;
-    if (w0 >> 31) {
+    if (paired) {   // wave-uniform: lanes 2i / 2i+1 hold the two halves of one entry, closed in the same slot
+      if (__any((int)(w0 >> 31))) {
+        double tot = acc + __shfl_xor(acc, 1, 64);          // even + odd, the same order in both lanes
+        if ((w0 >> 31) && !(vlane & 1)) {
+          int da = (w0 >> 18) & 63u, db = (w0 >> 24) & 63u;
+          double v = tot + (da == db ? diag : 0.0);
+          H[da * ldh + db] = v;
+          H[db * ldh + da] = v;
+        }
+        if (w0 >> 31) acc = 0.0;
+      }
+    } else if (w0 >> 31) {
       int da = (w0 >> 18) & 63u, db = (w0 >> 24) & 63u;
       double v = acc + (da == db ? diag : 0.0);
       H[da * ldh + db] = v;
@@ -340,7 +352,18 @@ __device__ __forceinline__ void hacc_phase(const IkLayout& L, double* sm, int st
       acc = 0.0;
     }
     acc += s1;
-    if (w1 >> 31) {
+    if (paired) {
+      if (__any((int)(w1 >> 31))) {
+        double tot = acc + __shfl_xor(acc, 1, 64);
+        if ((w1 >> 31) && !(vlane & 1)) {
+          int da = (w1 >> 18) & 63u, db = (w1 >> 24) & 63u;
+          double v = tot + (da == db ? diag : 0.0);
+          H[da * ldh + db] = v;
+          H[db * ldh + da] = v;
+        }
+        if (w1 >> 31) acc = 0.0;
+      }
+    } else if (w1 >> 31) {
       int da = (w1 >> 18) & 63u, db = (w1 >> 24) & 63u;
       double v = acc + (da == db ? diag : 0.0);
       H[da * ldh + db] = v;

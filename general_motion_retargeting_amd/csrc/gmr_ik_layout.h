@@ -17,7 +17,7 @@ struct IkLayout {
   // dimensions
   int nb, nh, nq, nv, nvp, nw, nhum, maxd, nhop, ldh;
   int tree_ok, tree_nt;          // limb/trunk decomposition usable by the 4-wavefront tree solver
-  int K[2], P[2], nitem[2], ntrip[2], nlanes;
+  int K[2], P[2], nitem[2], ntrip[2], nlanes, pair_lanes;
   // offsets in doubles
   int body_pos, body_quat, axis, range_lo, range_hi, scale, pos_off, quat_off;
   int wpos[2], wrot[2];
@@ -51,21 +51,28 @@ inline int ik_padded_nv(int nv) {
 // item word: [8:0] pair a, [17:9] pair b, [23:18] dof i, [29:24] dof j, [30] entry has no term,
 //            [31] last term of the entry
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t IK_ITEM_NOP = 1u << 30;   // contributes nothing (and, without bit 31, closes nothing)
+
 struct IkSchedule {
   int nlanes;                      // virtual lanes that share the assembly: 64 (one wave) or 192 (3 helpers)
+  int pair_lanes;                  // lanes [0, pair_lanes) cooperate pairwise on one entry each
   std::vector<uint32_t> items[2];
   std::vector<int> istart[2];      // nlanes + 1 offsets
   // what the kernel reads: every lane padded to ntrip slots with no-op words, stored [slot][lane] so that
   // a wave reads consecutive words (conflict-free) and the loop trip count is wave-uniform
   int ntrip[2];
+  int npaired[2];                  // entries split over a lane pair
   std::vector<uint32_t> padded[2];
 };
-
-constexpr uint32_t IK_ITEM_NOP = 1u << 30;   // contributes nothing, closes nothing
 
 inline IkSchedule make_ik_schedule(const gmr_model_t& m, const gmr_taskset_t& ts, int nlanes) {
   IkSchedule sch;
   sch.nlanes = nlanes;
+  // With three helper wavefronts (192 lanes) the longest entries (all tasks meet in the base x base
+  // block) bound the phase.  The first wavefront's 64 lanes therefore work in PAIRS: lanes 2i and 2i+1
+  // each sum half of the terms of one of the 32 heaviest entries, the halves are added with one
+  // shuffle (fixed order: even + odd) and the even lane stores.  sch.pair_lanes = 64 or 0.
+  sch.pair_lanes = nlanes > 64 ? 64 : 0;
   const int nv = m.nv;
   for (int s = 0; s < 2; s++) {
     std::vector<std::vector<uint32_t>> terms((size_t)nv * nv);
@@ -87,22 +94,50 @@ inline IkSchedule make_ik_schedule(const gmr_model_t& m, const gmr_taskset_t& ts
     std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.w > y.w; });
     std::vector<std::vector<Ent>> per_lane(nlanes);
     std::vector<int> load(nlanes, 0);
-    for (const Ent& e : ents) {
-      int best = 0;
-      for (int l = 1; l < nlanes; l++) if (load[l] < load[best]) best = l;
+    size_t first_single = 0;
+    if (sch.pair_lanes) {
+      // ents is sorted by weight: the heaviest pair_lanes/2 entries go to the lane pairs (marked da|64)
+      for (; first_single < ents.size() && (int)first_single < sch.pair_lanes / 2; first_single++) {
+        const Ent& e = ents[first_single];
+        if (e.w < 4) break;
+        per_lane[2 * first_single].push_back(e);
+        load[2 * first_single] = load[2 * first_single + 1] = 1 << 20;   // pair lanes take nothing else
+      }
+      for (int l = 2 * (int)first_single; l < sch.pair_lanes; l++) load[l] = 1 << 20;   // unused: the wavefront runs in pair mode
+    }
+    for (size_t ei = first_single; ei < ents.size(); ei++) {
+      const Ent& e = ents[ei];
+      int best = -1;
+      for (int l = 0; l < nlanes; l++) if (load[l] < (1 << 20) && (best < 0 || load[l] < load[best])) best = l;
       per_lane[best].push_back(e);
       load[best] += std::max(e.w, 1) + 1;  // +1: the two stores of the entry
     }
+    sch.npaired[s] = (int)first_single;
     sch.items[s].clear();
     sch.istart[s].assign(nlanes + 1, 0);
     for (int l = 0; l < nlanes; l++) {
       sch.istart[s][l] = (int)sch.items[s].size();
-      for (const Ent& e : per_lane[l]) {
-        const auto& t = terms[(size_t)e.da * nv + e.db];
+      const bool paired = l < 2 * sch.npaired[s];
+      if (paired) {
+        const Ent& e = per_lane[l & ~1][0];
+        const auto& tt = terms[(size_t)e.da * nv + e.db];
+        const size_t half = (tt.size() + 1) / 2;              // both lanes get `half` slots
+        const size_t lo2 = (l & 1) ? half : 0, hi2 = (l & 1) ? tt.size() : half;
         uint32_t dd = ((uint32_t)e.da << 18) | ((uint32_t)e.db << 24);
-        if (t.empty()) sch.items[s].push_back(dd | (1u << 30) | (1u << 31));
-        for (size_t i = 0; i < t.size(); i++)
-          sch.items[s].push_back(t[i] | dd | (i + 1 == t.size() ? (1u << 31) : 0u));
+        for (size_t i = 0; i < half; i++) {
+          const bool have = lo2 + i < hi2;
+          uint32_t w = (have ? tt[lo2 + i] : IK_ITEM_NOP) | dd;
+          if (i + 1 == half) w |= 1u << 31;                   // both lanes close the entry in the same slot
+          sch.items[s].push_back(w);
+        }
+        continue;
+      }
+      for (const Ent& e : per_lane[l]) {
+        const auto& tt = terms[(size_t)e.da * nv + e.db];
+        uint32_t dd = ((uint32_t)e.da << 18) | ((uint32_t)e.db << 24);
+        if (tt.empty()) sch.items[s].push_back(dd | (1u << 30) | (1u << 31));
+        for (size_t i = 0; i < tt.size(); i++)
+          sch.items[s].push_back(tt[i] | dd | (i + 1 == tt.size() ? (1u << 31) : 0u));
       }
     }
     sch.istart[s][nlanes] = (int)sch.items[s].size();
@@ -197,6 +232,7 @@ inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, co
   L.ldh = (m.nv % 2 == 0) ? m.nv + 1 : m.nv + 2;  // odd row stride (in doubles): conflict-free column reads
   for (int s = 0; s < 2; s++) { L.K[s] = ts.ntask[s]; L.P[s] = ts.npair[s]; L.nitem[s] = (int)sch.padded[s].size(); L.ntrip[s] = sch.ntrip[s]; }
   L.nlanes = sch.nlanes;
+  L.pair_lanes = sch.pair_lanes;
   int Kmax = std::max(L.K[0], L.K[1]);
   int Pmax = std::max(L.P[0], L.P[1]);
   int o = 0;

@@ -52,14 +52,18 @@ int main(int argc, char** argv) {
           uint32_t w = sch.items[s][i];
           std::pair<int, int> e = {(int)((w >> 18) & 63u), (int)((w >> 24) & 63u)};
           CHECK(e.first >= e.second && e.first < nv, "entry range");
+          const bool pairlane = l < 2 * sch.npaired[s];
           if (open) CHECK(e == cur, "terms of one entry must be contiguous in one lane");
-          else { CHECK(!closed.count(e), "entry (%d,%d) owned twice", e.first, e.second); cur = e; open = true; }
+          else { CHECK(pairlane ? (!(l & 1) ? !closed.count(e) : closed.count(e) == 1) : !closed.count(e),
+                       "entry (%d,%d) owned twice", e.first, e.second); cur = e; open = true; }
           if (!((w >> 30) & 1u)) got[e].insert({(int)(w & 511u), (int)((w >> 9) & 511u)});
           else got[e];
           if (w >> 31) { closed.insert(e); open = false; }
         }
         CHECK(!open, "lane %d ends inside an entry", l);
       }
+      for (int i = 0; i < sch.npaired[s]; i++)   // the two halves of a pair close in the same slot
+        CHECK(sch.istart[s][2 * i + 1] - sch.istart[s][2 * i] == sch.istart[s][2 * i + 2] - sch.istart[s][2 * i + 1], "pair %d halves differ in length", i);
       CHECK(got == want, "stage %d: schedule terms differ from J^T J structure (%zu vs %zu entries)", s, got.size(), want.size());
       CHECK(closed.size() == want.size(), "unclosed entries");
       int total = (int)sch.items[s].size();
