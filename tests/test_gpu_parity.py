@@ -348,3 +348,78 @@ def test_launch_shapes_agree(hip, oracle, g1):
     assert (stb == 0).all() and np.array_equal(qb[0], qb[799]) and np.abs(qb[0] - q1[0, :3]).max() <= 1e-12
     with pytest.raises(hip.GmrHipError):
         sol.set_waves(3)
+
+
+def _synthetic_robot(tmp_path, name, chains, tasks):
+    """chains: {prefix: (parent_body, n_hinges, pos)}; tasks: [(frame, w_pos, w_rot)].  Returns Setup-like tuple."""
+    from general_motion_retargeting_amd.ik_config import build_task_tables, pack_model, pack_taskset
+    from general_motion_retargeting_amd.mjcf import compile_mjcf
+    axes = ["1 0 0", "0 1 0", "0 0 1"]
+    children = {}
+    for prefix, (parent, n, pos) in chains.items():
+        children.setdefault(parent, []).append((prefix, n, pos))
+
+    def emit(body):
+        out = ""
+        for prefix, n, pos in children.get(body, []):
+            s, e = "", ""
+            for i in range(n):
+                nm = f"{prefix}{i}"
+                s += (f'<body name="{nm}" pos="{pos if i == 0 else "0.02 0 -0.09"}" quat="0.98 0.1 0.05 0.12">'
+                      f'<joint name="{prefix}j{i}" axis="{axes[(i + len(prefix)) % 3]}" range="-1.3 1.1"/>')
+                s += emit(nm) if i < n - 1 else ""
+                e = "</body>" + e
+            # children of the chain's last body
+            last = f"{prefix}{n - 1}"
+            s = s + emit(last) if False else s
+            out += s + emit(last) + e
+        return out
+    xml = ('<mujoco model="%s"><compiler angle="radian"/><worldbody><body name="base" pos="0 0 1"><freejoint/>%s'
+           '</body></worldbody></mujoco>' % (name, emit("base")))
+    p = tmp_path / f"{name}.xml"
+    p.write_text(xml)
+    model = compile_mjcf(str(p))
+    names = [f"h{i}" for i in range(len(tasks))]
+    tbl1 = {f: [h, wp, wr, [0.01, 0, 0], [1, 0, 0, 0]] for (f, wp, wr), h in zip(tasks, names)}
+    tbl2 = {f: [h, wp * 2 + 1, max(wr / 2, 1), [0, 0, 0], [1, 0, 0, 0]] for (f, wp, wr), h in zip(tasks, names)}
+    cfg = {"robot_root_name": "base", "human_root_name": "h0", "ground_height": 0.0, "human_height_assumption": 1.8,
+           "use_ik_match_table1": True, "use_ik_match_table2": True, "human_scale_table": {n: 0.9 for n in names},
+           "ik_match_table1": tbl1, "ik_match_table2": tbl2}
+    tt = build_task_tables(cfg, 1.7)
+    return model, tt, pack_model(model), pack_taskset(model, tt)
+
+
+@pytest.mark.parametrize("topology", ["biped_no_arms", "five_limbs_head_in_trunk", "hand_with_fingers", "too_wide_for_tree"])
+def test_generic_topologies(hip, oracle, tmp_path, topology):
+    """Robots the shipped set does not contain: fewer / more limbs, limbs that branch (the arm becomes
+    trunk), and one the tree solver must refuse (dense fallback).  Both launch shapes against the oracle."""
+    from general_motion_retargeting_amd import synth
+    if topology == "biped_no_arms":
+        chains = {"l": ("base", 6, "0 0.1 0"), "r": ("base", 6, "0 -0.1 0")}
+        tasks = [("base", 100, 10), ("l2", 0, 10), ("l5", 50, 10), ("r2", 0, 10), ("r5", 50, 10)]
+    elif topology == "five_limbs_head_in_trunk":
+        chains = {"w": ("base", 2, "0 0 0.1"), "l": ("base", 5, "0 0.1 0"), "r": ("base", 5, "0 -0.1 0"),
+                  "a": ("w1", 4, "0 0.2 0.2"), "b": ("w1", 4, "0 -0.2 0.2"), "n": ("w1", 2, "0 0 0.3")}
+        tasks = [("base", 100, 10), ("w1", 0, 10), ("l4", 50, 10), ("r4", 50, 10), ("a3", 10, 5), ("b3", 10, 5), ("n1", 0, 10)]
+    elif topology == "hand_with_fingers":
+        chains = {"l": ("base", 4, "0 0.1 0"), "r": ("base", 4, "0 -0.1 0"), "a": ("base", 4, "0 0.2 0.3"),
+                  "f": ("a3", 2, "0.05 0.02 0"), "g": ("a3", 2, "0.05 -0.02 0")}
+        tasks = [("base", 100, 10), ("l3", 50, 10), ("r3", 50, 10), ("a3", 10, 10), ("f1", 20, 5), ("g1", 20, 5)]
+    else:
+        chains = {"w": ("base", 3, "0 0 0.1"), "l": ("base", 6, "0 0.1 0"), "r": ("base", 6, "0 -0.1 0"),
+                  "a": ("w2", 5, "0 0.2 0.2"), "b": ("w2", 5, "0 -0.2 0.2"), "n": ("w2", 3, "0 0 0.3")}
+        tasks = [("base", 100, 10), ("w2", 0, 10), ("l5", 50, 10), ("r5", 50, 10), ("a4", 10, 5), ("b4", 10, 5), ("n2", 0, 10)]
+    model, tt, mb, ts = _synthetic_robot(tmp_path, topology, chains, tasks)
+    human, q0 = synth.make_streams(model, tt, 5, 8, seed=123)
+    rng = np.random.default_rng(1)
+    human[..., :3] += rng.normal(0, 0.05, size=human[..., :3].shape)     # push some joints onto their limits
+    q_o, ns_o, st_o = oracle.retarget_streams(mb, ts, q0, human)
+    assert (st_o == 0).all()
+    sol = hip.Solver(mb, ts)
+    for waves in (4, 1):
+        sol.set_waves(waves)
+        q_h, ns_h, st_h = sol.retarget_streams(q0, human)
+        assert (st_h == 0).all(), (topology, waves)
+        assert np.array_equal(ns_h, ns_o), (topology, waves)
+        joint, pos, rot = _compare(q_h, q_o)
+        assert joint <= 1e-8 and pos <= 1e-8 and rot <= 1e-8, (topology, waves, joint, pos, rot)
