@@ -373,6 +373,46 @@ __device__ __forceinline__ void hacc_phase(const IkLayout& L, double* sm, int st
   }
 }
 
+// (d') one wavefront per stream: the schedule is read from the global image (the same words for every
+// stream on the CU: vector-L1 hits) instead of LDS, four slots per trip with the next trip in flight.
+__device__ __forceinline__ void hacc_phase_g(const IkLayout& L, double* sm, int stage,
+                                             const uint32_t* __restrict__ gitems, double diag, int lane) {
+  const int ldh = L.ldh, ntrip = L.ntrip[stage];          // a multiple of 4, 64 lanes
+  double* __restrict__ H = sm + L.H;
+  const double* __restrict__ J = sm + L.Jw;
+  const uint32_t* p = gitems + lane;
+  uint32_t n[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) n[k] = p[k * 64];
+  double acc = 0.0;
+  for (int it = 0; it < ntrip; it += 4) {
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = n[k];
+    if (it + 4 < ntrip) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) n[k] = p[(it + 4 + k) * 64];
+    }
+    double s[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      s[k] = dot6v(J + 6 * (w[k] & 511u), J + 6 * ((w[k] >> 9) & 511u));
+      if ((w[k] >> 30) & 1u) s[k] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      acc += s[k];
+      if (w[k] >> 31) {
+        int da = (w[k] >> 18) & 63u, db = (w[k] >> 24) & 63u;
+        double v = acc + (da == db ? diag : 0.0);
+        H[da * ldh + db] = v;
+        H[db * ldh + da] = v;
+        acc = 0.0;
+      }
+    }
+  }
+}
+
 // the whole assembly as seen from the MAIN wave.  NW == 1: all four phases by this wave.  NW > 1:
 // the Jacobian columns are shared by all NW waves, then the helpers assemble H (64*(NW-1) virtual
 // lanes) while this wave gathers c and the bounds; three workgroup barriers per assembly.
@@ -392,7 +432,7 @@ __device__ __forceinline__ void build_qp_main(const IkLayout& L, double* sm, int
     cvec_phase(L, sm, stage, tb, limited, limit_gain, lane);
     PROF_END(pr, PH_CVEC);
     PROF_BEGIN(pr);
-    hacc_phase(L, sm, stage, tb, diag, lane);
+    hacc_phase_g(L, sm, stage, tb.items, diag, lane);
     WSYNC();
     PROF_END(pr, PH_HACC);
   } else {
@@ -745,7 +785,8 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
       for (int stage = 0; stage < 2; stage++) {
         if (!(stage == 0 ? use0 : use1)) continue;
         const StageTabs tb = {si + L.i_task_body[stage], si + L.i_task_human[stage], si + L.i_pair_task[stage],
-                              si + L.i_pair_dof[stage], si + L.i_pair_index[stage], sw + L.w_items[stage]};
+                              si + L.i_pair_dof[stage], si + L.i_pair_index[stage],
+                              NW == 1 ? reinterpret_cast<const uint32_t*>(image) + L.g_items[stage] : sw + L.w_items[stage]};
         const int K = L.K[stage];
         if (h_stage != stage) {
           // structural zeros of H are never written by the schedule: clear when the pattern changes

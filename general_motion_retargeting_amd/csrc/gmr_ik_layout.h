@@ -26,6 +26,9 @@ struct IkLayout {
   // offsets in 32-bit words (after the doubles): the H-assembly schedule
   int w_items[2], w_istart[2], w_ctl, w_tr_mask, w_tr_cnt;
   int n_word;
+  // nw == 1: the schedule stays in the global image (read through the vector L1, identical for all streams)
+  // at these 32-bit word offsets from the image start; -1 when it lives in LDS (w_items)
+  int g_items[2], image_bytes;
   // offsets in shorts (after the words)
   int i_hop, i_depth, i_body_hinge, i_hinge_body, i_limited, i_is_foot, i_tree_limb, i_tree_trunk;
   int i_task_body[2], i_task_human[2], i_pair_task[2], i_pair_dof[2], i_pair_index[2];
@@ -143,7 +146,8 @@ inline IkSchedule make_ik_schedule(const gmr_model_t& m, const gmr_taskset_t& ts
     sch.istart[s][nlanes] = (int)sch.items[s].size();
     int nt = 0;
     for (int l = 0; l < nlanes; l++) nt = std::max(nt, sch.istart[s][l + 1] - sch.istart[s][l]);
-    nt = (nt + 1) & ~1;                       // two slots per loop trip
+    nt = nlanes == 64 ? (nt + 3) & ~3         // four slots per loop trip (items streamed from global memory)
+                      : (nt + 1) & ~1;        // two slots per loop trip
     sch.ntrip[s] = nt;
     sch.padded[s].assign((size_t)nt * nlanes, IK_ITEM_NOP);
     for (int l = 0; l < nlanes; l++)
@@ -242,20 +246,32 @@ inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, co
   L.scale = D(L.nhum); L.pos_off = D(3 * L.nhum); L.quat_off = D(4 * L.nhum);
   for (int s = 0; s < 2; s++) { L.wpos[s] = D(L.K[s]); L.wrot[s] = D(L.K[s]); }
   L.q = D(L.nq + 1);
-  L.xa = D(7 * L.nb + 1); L.xb = D(7 * L.nb + 1);   // ping-pong (pos, quat) of the FK rounds
+  L.xa = D(7 * L.nb + 1);                            // FK result; the second buffer of the FK rounds aliases Jw
   L.xaxis = D(3 * L.nb);
-  L.raw = D(7 * L.nhum + 1); L.tgt = D(7 * L.nhum + 1);
-  L.e = D(6 * Kmax); L.eaux = D(3 * Kmax); L.we = D(6 * Kmax); L.M = D(18 * Kmax);
+  L.tgt = D(7 * L.nhum + 1);
+  L.e = D(6 * Kmax); L.eaux = D(3 * Kmax); L.we = D(6 * Kmax);
+  L.M = D(std::max(18 * Kmax, 7 * L.nhum + 1));
+  L.raw = L.M;                                // the raw frame is consumed by the preprocess step, before any solve
   if (o & 1) o++;                             // Jw rows (48 B) are read as three 16-B pieces
-  L.Jw = D(6 * Pmax); L.cpart = D(Pmax);
+  L.Jw = D(std::max(6 * Pmax, 7 * L.nb + 1)); L.cpart = D(Pmax);
+  L.xb = L.Jw;                                // FK runs between solves, when the assembly scratch is dead
+  // The transpose scratch of the QP solvers (dense: nvp x (nvp+1); tree: 4 x 18 x 19) is only live inside a
+  // solve, when the assembly scratch [e, eaux, we, M, Jw, cpart] is dead: alias it there (saves ~11 KB of
+  // LDS per stream = one more resident workgroup per CU in the throughput shape).
+  {
+    const int need = std::max(L.nvp * (L.nvp + 1), nw == 4 ? 4 * 18 * 19 : 0);
+    const int have = o - L.e;
+    if (have < need) D(need - have);
+    L.Kt = L.e;
+  }
+  if (o & 1) o++;
   L.H = D(L.nv * L.ldh + 2);
-  L.Kt = D(std::max(L.nvp * (L.nvp + 1), nw == 4 ? 4 * 18 * 19 : 0));   // dense transpose / 4 tree-solver scratches
   L.c = D(L.nv); L.x = D(L.nv); L.lo = D(L.nv); L.hi = D(L.nv); L.scal = D(2);
   L.tr_spart = D(nw == 4 ? 4 * 10 * 10 : 0); L.tr_rpart = D(nw == 4 ? 4 * 10 : 0);
   L.n_double = o;
   int w = 0;
   auto W = [&](int n) { int r = w; w += n; return r; };
-  for (int s = 0; s < 2; s++) { L.w_items[s] = W(L.nitem[s]); L.w_istart[s] = 0; }
+  for (int s = 0; s < 2; s++) { L.w_items[s] = nw == 1 ? 0 : W(L.nitem[s]); L.w_istart[s] = 0; L.g_items[s] = -1; }
   L.w_ctl = W(2);
   if (w % 2) w++;
   L.w_tr_mask = W(16); L.w_tr_cnt = W(4);
@@ -272,7 +288,10 @@ inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, co
     L.i_pair_index[s] = I(GMR_MAX_TASKS * L.nv);
   }
   L.n_short = i;
-  L.smem_bytes = L.n_double * 8 + L.n_word * 4 + ((L.n_short * 2 + 15) / 16) * 16;
+  L.smem_bytes = (L.n_double * 8 + L.n_word * 4 + L.n_short * 2 + 15) / 16 * 16;
+  L.image_bytes = (L.smem_bytes + 15) / 16 * 16;
+  if (nw == 1)
+    for (int s = 0; s < 2; s++) { L.g_items[s] = L.image_bytes / 4; L.image_bytes += (L.nitem[s] * 4 + 15) / 16 * 16; }
   return L;
 }
 
@@ -295,7 +314,7 @@ inline IkParams make_ik_params(const gmr_model_t& m, const gmr_taskset_t& ts) {
 // (matters for the per-frame entry point, where the prologue is paid on every call).
 inline std::vector<char> make_ik_image(const gmr_model_t& m, const gmr_taskset_t& ts, const IkSchedule& sch,
                                        const IkLayout& L) {
-  std::vector<char> img(((size_t)L.smem_bytes + 15) / 16 * 16, 0);
+  std::vector<char> img((size_t)L.image_bytes, 0);
   double* sm = reinterpret_cast<double*>(img.data());
   uint32_t* sw = reinterpret_cast<uint32_t*>(sm + L.n_double);
   short* si = reinterpret_cast<short*>(sw + L.n_word);
@@ -331,7 +350,8 @@ inline std::vector<char> make_ik_image(const gmr_model_t& m, const gmr_taskset_t
     si[L.i_is_foot + i] = (short)ts.is_foot[i];
   }
   for (int s = 0; s < 2; s++) {
-    for (size_t i = 0; i < sch.padded[s].size(); i++) sw[L.w_items[s] + i] = sch.padded[s][i];
+    uint32_t* dst = L.g_items[s] >= 0 ? reinterpret_cast<uint32_t*>(img.data()) + L.g_items[s] : sw + L.w_items[s];
+    for (size_t i = 0; i < sch.padded[s].size(); i++) dst[i] = sch.padded[s][i];
     for (int k = 0; k < L.K[s]; k++) {
       si[L.i_task_body[s] + k] = (short)ts.task_body[s][k];
       si[L.i_task_human[s] + k] = (short)ts.task_human[s][k];

@@ -101,6 +101,7 @@ int main(int argc, char** argv) {
     // no coupling between different limbs: no dof of one limb is an ancestor of a dof of another
   }
   // layouts
+  int lds[2] = {0, 0}, nd[2] = {0, 0}, nwd[2] = {0, 0};
   for (int nw : {1, 4}) {
     gmr::IkSchedule sch = gmr::make_ik_schedule(m, ts, nw == 1 ? 64 : 192);
     gmr::IkLayout L = gmr::make_ik_layout(m, ts, sch, nw);
@@ -110,7 +111,14 @@ int main(int argc, char** argv) {
     std::vector<char> img = gmr::make_ik_image(m, ts, sch, L);
     CHECK((int)img.size() >= L.smem_bytes && img.size() % 16 == 0, "image size");
     CHECK(L.tree_ok == ((nw == 4 && tr.ok) ? 1 : 0), "tree flag");
+    {   // the QP transpose scratch may alias the assembly scratch, never H / c / x / lo / hi
+      const int need = std::max(L.nvp * (L.nvp + 1), nw == 4 ? 4 * 18 * 19 : 0);
+      CHECK(L.Kt >= L.e && L.Kt + need <= L.H, "Kt [%d,%d) overlaps H at %d", L.Kt, L.Kt + need, L.H);
+      CHECK(L.H + nv * L.ldh <= L.c, "H overlaps c");
+    }
+    lds[nw == 4] = L.smem_bytes; nd[nw == 4] = L.n_double; nwd[nw == 4] = L.n_word;
   }
-  std::printf("ok nv=%d tree=%d limbs=%d trunk=%d\n", nv, (int)tr.ok, nlimb, tr.nt);
+  std::printf("ok nv=%d tree=%d limbs=%d trunk=%d lds1=%d (%d doubles, %d words) lds4=%d (%d doubles, %d words)\n", nv, (int)tr.ok, nlimb, tr.nt,
+              lds[0], nd[0], nwd[0], lds[1], nd[1], nwd[1]);
   return 0;
 }
