@@ -26,9 +26,9 @@ extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree*, int, int, int, con
                                           float*, float*, float*, float*, hipStream_t);
 extern "C" int gmr_fk_blocks(int nbody, int B);
 
-// up to this many streams a launch uses the 4-wave (main + 3 helpers) shape: 768 streams x 4 waves fill
-// the 3 LDS-limited workgroup slots of every CU
-#define GMR_HELPER_MAX_STREAMS 768
+// up to this many streams a launch uses the 4-wave (main + 3 helpers) shape; measured crossover on MI355X
+// (tools/shape_sweep.py, G1): S=384 1.05M vs 1.02M frames/s, S=512 1.02M vs 1.32M (NW=4 vs NW=1)
+#define GMR_HELPER_MAX_STREAMS 400
 
 namespace {
 thread_local char g_err[512] = "";

@@ -215,6 +215,23 @@ class GeneralMotionRetargeting:
         self.configuration.data.qpos = q_out[0, 0].copy()
         return self.configuration.data.qpos.copy()
 
+    def retarget_packed(self, frame: np.ndarray, offset_to_ground=False) -> np.ndarray:
+        """:meth:`retarget` for a frame that is already packed (``f64[nhuman, 7]``, rows in
+        ``human_body_names`` order, NaN rows = absent bodies): the streaming path (utils/optitrack.py)."""
+        frame = np.ascontiguousarray(frame, dtype=np.float64)
+        if frame.shape != (len(self._human_names), 7):
+            raise ValueError(f"packed frame must be [{len(self._human_names)}, 7], got {frame.shape}")
+        self._raw_frame = frame
+        self._scaled_src, self._scaled_cache = None, None
+        q_out, nsolve, status = self.hip_solver.retarget_streams(
+            self.configuration.data.qpos[None], frame[None, None],
+            flags=_lib.FLAG_OFFSET_TO_GROUND if offset_to_ground else 0)
+        if status[0] != 0:
+            raise RuntimeError(f"IK failed (status {int(status[0])}): QP not solvable / non-finite input")
+        self.last_num_solves = nsolve[0, 0].copy()
+        self.configuration.data.qpos = q_out[0, 0].copy()
+        return self.configuration.data.qpos.copy()
+
     def retarget_clip(self, frames, offset_to_ground=False) -> np.ndarray:
         """All frames of one clip in ONE launch (time loop on device); continues from the current
         configuration exactly like calling :meth:`retarget` per frame.  ``frames`` is a sequence of

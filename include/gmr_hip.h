@@ -70,7 +70,7 @@ int gmr_solver_create(const gmr_model_t* model, const gmr_taskset_t* taskset, gm
 int gmr_solver_destroy(gmr_solver_t* solver);
 int gmr_solver_dims(const gmr_solver_t* solver, int* nq, int* nv, int* nhuman);
 /* Launch shape of the IK kernel: 1 = one wavefront per stream (most streams resident), 4 = one main
- * wavefront + 3 helper wavefronts per stream (shortest per-frame latency), 0 = automatic (4 up to 768
+ * wavefront + 3 helper wavefronts per stream (shortest per-frame latency), 0 = automatic (4 up to 400
  * streams per launch, 1 above).  Results agree to rounding between the shapes; no reference analogue. */
 int gmr_solver_set_waves(gmr_solver_t* solver, int waves_per_stream);
 

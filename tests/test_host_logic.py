@@ -110,6 +110,24 @@ def test_dataset_postprocess_matches_reference_recipe(oracle, g1, monkeypatch):
         save_robot_motion(p, md)
         data, fps, rp, rr, dp, lbp, names = load_robot_motion(p)
         assert fps == 30.0 and np.array_equal(rr, qpos[:, 3:7]) and names == km.body_names
+        # N3: the list-valued, protocol-2 variant (convert_pkl_for_training.py:44-74) and what the
+        # training-side MotionLoader extracts from either file (motion_loader.py:72-98)
+        import pickle
+        from general_motion_retargeting_amd.data_loader import motion_arrays
+        p2 = os.path.join(d, "m2.pkl")
+        save_robot_motion(p2, md, training_compatible=True)
+        with open(p2, "rb") as f:
+            raw = f.read()
+        assert raw[:2] == b"\x80\x02"                                  # pickle protocol 2
+        conv = pickle.loads(raw)
+        assert all(not isinstance(v, np.ndarray) for v in conv.values())
+        assert isinstance(conv["root_pos"], list) and conv["fps"] == 30.0 and conv["link_body_list"] == km.body_names
+        a, b = motion_arrays(data), motion_arrays(conv)
+        for k in ("root_pos", "root_rot", "dof_pos", "local_body_pos"):
+            assert a[k].dtype == np.float32 and np.array_equal(a[k], b[k])
+        assert a["num_frames"] == len(qpos) and abs(a["motion_duration"] - len(qpos) / 30.0) < 1e-12
+        data2, _, _, rr2, _, _, _ = load_robot_motion(p2)              # the loader accepts the list form too
+        assert np.array_equal(rr2, qpos[:, 3:7])
 
 
 def test_synthetic_generator_is_seeded_and_invertible(oracle, g1):
