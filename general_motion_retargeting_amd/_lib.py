@@ -56,6 +56,15 @@ _SIGS = {
                                    C.c_void_p, C.c_void_p]),
     "gmr_fk_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p]),
+    "gmr_smplx_create": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gmr_smplx_destroy": (C.c_int, [C.c_void_p]),
+    "gmr_smplx_rows": (C.c_int, [C.c_void_p]),
+    "gmr_smplx_joints_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gmr_smplx_joints": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gmr_smplx_align_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
+    "gmr_smplx_align": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                  C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
@@ -273,6 +282,67 @@ class FkHandle:
     def close(self):
         if self.handle:
             lib().gmr_fk_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SmplxHandle:
+    """Kinematic tree + joint selection behind gmr_smplx_create (N1: SMPL-X frame extraction)."""
+
+    def __init__(self, parents, sel=None):
+        require_gpu()
+        self.parents = np.ascontiguousarray(parents, dtype=np.int32)
+        self.J = int(len(self.parents))
+        self.sel = None if sel is None else np.ascontiguousarray(sel, dtype=np.int32)
+        h = C.c_void_p()
+        check(lib().gmr_smplx_create(self.J, _ptr(self.parents), 0 if self.sel is None else len(self.sel),
+                                     _ptr(self.sel), C.byref(h)))
+        self.handle = h
+        self.rows = int(lib().gmr_smplx_rows(h))
+
+    def joints(self, j_rest, full_pose, transl):
+        j_rest = np.ascontiguousarray(j_rest, dtype=np.float64)
+        full_pose = np.ascontiguousarray(full_pose, dtype=np.float32).reshape(-1, self.J, 3)
+        transl = np.ascontiguousarray(transl, dtype=np.float32).reshape(-1, 3)
+        N = full_pose.shape[0]
+        if j_rest.shape != (self.J, 3) or transl.shape[0] != N:
+            raise ValueError("shape mismatch in smplx joints inputs")
+        out = np.zeros((N, self.J, 3), dtype=np.float32)
+        check(lib().gmr_smplx_joints(self.handle, N, _ptr(j_rest), _ptr(full_pose), _ptr(transl), _ptr(out)))
+        return out
+
+    def align(self, full_pose, joints, target_time=None):
+        full_pose = np.ascontiguousarray(full_pose, dtype=np.float32).reshape(-1, self.J, 3)
+        joints = np.ascontiguousarray(joints, dtype=np.float32)
+        N = full_pose.shape[0]
+        if joints.ndim != 3 or joints.shape[0] != N or joints.shape[1] < self.J or joints.shape[2] != 3:
+            raise ValueError("joints must be [N, >=J, 3]")
+        tt = None if target_time is None else np.ascontiguousarray(target_time, dtype=np.float64)
+        nout = N if tt is None else int(len(tt))
+        out = np.zeros((nout, self.rows, 7), dtype=np.float64)
+        check(lib().gmr_smplx_align(self.handle, N, int(joints.shape[1]), _ptr(full_pose), _ptr(joints), nout, _ptr(tt),
+                                    _ptr(out)))
+        return out
+
+    def align_dev(self, N, jstride, d_full_pose, d_joints, nout, d_target_time, d_out, stream=None):
+        def p(x):
+            return x.ptr if isinstance(x, DeviceBuffer) else x
+        check(lib().gmr_smplx_align_dev(self.handle, int(N), int(jstride), p(d_full_pose), p(d_joints), int(nout),
+                                        p(d_target_time), p(d_out), stream))
+
+    def joints_dev(self, N, d_j_rest, d_full_pose, d_transl, d_joints, stream=None):
+        def p(x):
+            return x.ptr if isinstance(x, DeviceBuffer) else x
+        check(lib().gmr_smplx_joints_dev(self.handle, int(N), p(d_j_rest), p(d_full_pose), p(d_transl), p(d_joints), stream))
+
+    def close(self):
+        if self.handle:
+            lib().gmr_smplx_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

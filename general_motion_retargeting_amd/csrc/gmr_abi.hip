@@ -12,6 +12,7 @@
 #include "../../include/gmr_hip.h"
 #include "gmr_fk_tree.h"
 #include "gmr_ik_layout.h"
+#include "gmr_internal.h"
 
 static_assert(sizeof(gmr_model_t) % 8 == 0, "gmr_model_t must be 8-byte sized");
 static_assert(sizeof(gmr_taskset_t) % 8 == 0, "gmr_taskset_t must be 8-byte sized");
@@ -32,13 +33,16 @@ extern "C" int gmr_fk_blocks(int nbody, int B);
 
 namespace {
 thread_local char g_err[512] = "";
-int fail(int code, const char* fmt, ...) {
+}
+int gmr_fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof g_err, fmt, ap);
   va_end(ap);
   return code;
 }
+namespace {
+#define fail gmr_fail
 #define HIP_TRY(call)                                                                         \
   do {                                                                                        \
     hipError_t _e = (call);                                                                   \

@@ -1,0 +1,414 @@
+// gmr_smplx.hip -- SMPL-X frame extraction on the device: the step in
+// front of the retargeting loop.  Replaces, for a whole clip in one launch each,
+//   * the joints-only part of the body-model forward pass called at utils/smpl.py:12-34
+//     (smplx_joints_kernel; the mesh, 10 475 vertices, is never needed by GMR), and
+//   * get_smplx_data_offline_fast / get_smplx_data (utils/smpl.py:44-197): SLERP fps alignment of every
+//     local joint rotation, linear interpolation of the joint positions, chain of global orientations
+//     (smplx_align_kernel), writing the packed human[T'][nhuman][7] frames the IK kernel consumes.
+//
+// Mapping: lane = output frame.  The tree is walked in DFS order (host-built program); the transform of the
+// ancestor at depth d sits in a lane-private LDS column stack[d][.][lane] (conflict-free), so LDS holds
+// max_depth, not J, transforms.  Both kernels are streaming (read 2 pose rows + 2 joint rows, write nsel x 56 B
+// per frame); the transcendental chain per joint makes them FP64-VALU bound well below the HBM roof, three
+// orders of magnitude above the IK kernel's frame rate, so they are written for exactness, not tuned.
+//
+// Arithmetic follows the SciPy formulas the reference goes through (from_rotvec / as_rotvec small-angle
+// series at 1e-3, from_quat normalisation, interp1d's float32 difference); see oracle/gmr_oracle_smplx.c.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "../../include/gmr_hip.h"
+#include "gmr_internal.h"
+
+#define SX_MAX_JOINTS 64
+#define SX_BLOCK 64
+
+namespace gmr {
+
+struct SmplxProg {
+  int n;                         // joints visited (DFS order)
+  int J;                         // joints per pose row
+  int nrow;                      // rows written per frame
+  int max_depth;                 // stack levels
+  short joint[SX_MAX_JOINTS];    // joint index of step k
+  short depth[SX_MAX_JOINTS];    // its depth (root = 0)
+  short row[SX_MAX_JOINTS];      // output row or -1
+  short parent[SX_MAX_JOINTS];   // parent JOINT index of step k (joints kernel: rest offsets)
+};
+
+struct q4 { double x, y, z, w; };   // xyzw like SciPy
+
+__device__ __forceinline__ q4 sx_from_rotvec(double vx, double vy, double vz) {
+  const double a = sqrt(vx * vx + vy * vy + vz * vz);
+  double scale;
+  if (a <= 1e-3) {
+    const double a2 = a * a;
+    scale = 0.5 - a2 / 48.0 + a2 * a2 / 3840.0;
+  } else {
+    scale = sin(a / 2.0) / a;
+  }
+  return q4{scale * vx, scale * vy, scale * vz, cos(a / 2.0)};
+}
+
+__device__ __forceinline__ q4 sx_normalize(q4 q) {
+  const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  return q4{q.x / n, q.y / n, q.z / n, q.w / n};
+}
+
+__device__ __forceinline__ q4 sx_compose(q4 p, q4 q) {
+  const double cx = p.y * q.z - p.z * q.y, cy = p.z * q.x - p.x * q.z, cz = p.x * q.y - p.y * q.x;
+  q4 r;
+  r.x = p.w * q.x + q.w * p.x + cx;
+  r.y = p.w * q.y + q.w * p.y + cy;
+  r.z = p.w * q.z + q.w * p.z + cz;
+  r.w = p.w * q.w - p.x * q.x - p.y * q.y - p.z * q.z;
+  return sx_normalize(r);
+}
+
+// slerp() of utils/smpl.py:76-107 followed by .as_rotvec() and from_rotvec() again (:140, :181-186)
+__device__ __forceinline__ q4 sx_slerp_local(q4 q1, q4 q2, double t) {
+  q1 = sx_normalize(q1);
+  q2 = sx_normalize(q2);
+  double dot = q1.x * q2.x + q1.y * q2.y + q1.z * q2.z + q1.w * q2.w;
+  if (dot < 0.0) { q2 = q4{-q2.x, -q2.y, -q2.z, -q2.w}; dot = -dot; }
+  q4 q;
+  if (dot > 0.9995) {
+    q = q4{q1.x + t * (q2.x - q1.x), q1.y + t * (q2.y - q1.y), q1.z + t * (q2.z - q1.z), q1.w + t * (q2.w - q1.w)};
+  } else {
+    const double th0 = acos(dot), th = th0 * t;
+    const double st = sin(th), st0 = sin(th0);
+    const double s0 = cos(th) - dot * st / st0, s1 = st / st0;
+    q = q4{s0 * q1.x + s1 * q2.x, s0 * q1.y + s1 * q2.y, s0 * q1.z + s1 * q2.z, s0 * q1.w + s1 * q2.w};
+  }
+  q = sx_normalize(q);
+  // as_rotvec
+  if (q.w < 0) q = q4{-q.x, -q.y, -q.z, -q.w};
+  const double a = 2.0 * atan2(sqrt(q.x * q.x + q.y * q.y + q.z * q.z), q.w);
+  double scale;
+  if (a <= 1e-3) {
+    const double a2 = a * a;
+    scale = 2.0 + a2 / 12.0 + 7.0 * a2 * a2 / 2880.0;
+  } else {
+    scale = a / sin(a / 2.0);
+  }
+  return sx_from_rotvec(scale * q.x, scale * q.y, scale * q.z);
+}
+
+#pragma clang fp contract(off)
+
+// out[Nout][nrow][7]: pos xyz, quat wxyz.  ALIGN: target_time[Nout] (np.linspace(0, N-1, Nout)); else Nout == N.
+template <bool ALIGN>
+__global__ __launch_bounds__(SX_BLOCK) void smplx_align_kernel(SmplxProg P, int N, int jstride,
+                                                               const float* __restrict__ full_pose,
+                                                               const float* __restrict__ joints, int Nout,
+                                                               const double* __restrict__ target_time,
+                                                               double* __restrict__ out) {
+  extern __shared__ __align__(16) double stack[];   // [max_depth][4][SX_BLOCK]
+  const int lane = threadIdx.x;
+  const int o = blockIdx.x * SX_BLOCK + lane;
+  if (o >= Nout) return;                             // no barriers in this kernel: columns are lane-private
+  double t = 0.0, alpha = 0.0;
+  int idx1 = o, idx2 = o, lo = o, hi = o;
+  if (ALIGN) {
+    t = target_time[o];
+    idx1 = (int)floor(t);
+    idx1 = min(max(idx1, 0), N - 1);
+    idx2 = min(idx1 + 1, N - 1);
+    alpha = t - (double)idx1;
+    int ss = (int)ceil(t);
+    ss = min(max(ss, 1), N - 1);
+    lo = ss - 1; hi = ss;
+  }
+  const float* p1 = full_pose + (size_t)idx1 * P.J * 3;
+  const float* p2 = full_pose + (size_t)idx2 * P.J * 3;
+  const float* jl = joints + (size_t)lo * jstride * 3;
+  const float* jh = joints + (size_t)hi * jstride * 3;
+  double* orow = out + (size_t)o * P.nrow * 7;
+  for (int k = 0; k < P.n; k++) {
+    const int j = P.joint[k], d = P.depth[k];
+    q4 ql;
+    if (ALIGN) {
+      q4 qa = sx_from_rotvec((double)p1[3 * j], (double)p1[3 * j + 1], (double)p1[3 * j + 2]);
+      q4 qb = sx_from_rotvec((double)p2[3 * j], (double)p2[3 * j + 1], (double)p2[3 * j + 2]);
+      ql = sx_slerp_local(qa, qb, alpha);
+    } else {
+      ql = sx_from_rotvec((double)p1[3 * j], (double)p1[3 * j + 1], (double)p1[3 * j + 2]);
+    }
+    q4 qg = ql;
+    if (d > 0) {
+      const double* s = stack + (size_t)(d - 1) * 4 * SX_BLOCK + lane;
+      qg = sx_compose(q4{s[0], s[SX_BLOCK], s[2 * SX_BLOCK], s[3 * SX_BLOCK]}, ql);
+    }
+    {
+      double* s = stack + (size_t)d * 4 * SX_BLOCK + lane;
+      s[0] = qg.x; s[SX_BLOCK] = qg.y; s[2 * SX_BLOCK] = qg.z; s[3 * SX_BLOCK] = qg.w;
+    }
+    const int r = P.row[k];
+    if (r >= 0) {
+      double* w = orow + r * 7;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        if (ALIGN) {
+          const float ylo = jl[3 * j + c], yhi = jh[3 * j + c];
+          const float df = yhi - ylo;                                  // float32 difference (interp1d on a float32 y)
+          const double slope = (double)df / (double)(hi - lo);
+          w[c] = slope * (t - (double)lo) + (double)ylo;
+        } else {
+          w[c] = (double)jl[3 * j + c];
+        }
+      }
+      w[3] = qg.w; w[4] = qg.x; w[5] = qg.y; w[6] = qg.z;
+    }
+  }
+}
+
+// joints f32[N][J][3] from rest joints f64[J][3], poses f32[N][J][3], translations f32[N][3]
+__global__ __launch_bounds__(SX_BLOCK) void smplx_joints_kernel(SmplxProg P, int N, const double* __restrict__ j_rest,
+                                                                const float* __restrict__ full_pose,
+                                                                const float* __restrict__ transl,
+                                                                float* __restrict__ joints) {
+  extern __shared__ __align__(16) double stack[];   // [max_depth][12][SX_BLOCK]: R row-major, p
+  const int lane = threadIdx.x;
+  const int n = blockIdx.x * SX_BLOCK + lane;
+  if (n >= N) return;
+  const float* pr = full_pose + (size_t)n * P.J * 3;
+  const double tx = transl[(size_t)n * 3], ty = transl[(size_t)n * 3 + 1], tz = transl[(size_t)n * 3 + 2];
+  float* jo = joints + (size_t)n * P.J * 3;
+  for (int k = 0; k < P.n; k++) {
+    const int j = P.joint[k], d = P.depth[k];
+    const double vx = pr[3 * j], vy = pr[3 * j + 1], vz = pr[3 * j + 2];
+    const double ax = vx + 1e-8, ay = vy + 1e-8, az = vz + 1e-8;
+    const double ang = sqrt(ax * ax + ay * ay + az * az);
+    const double x = vx / ang, y = vy / ang, z = vz / ang, s = sin(ang), c1 = 1.0 - cos(ang);
+    const double K[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+    double Rl[9];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        double acc = 0;
+#pragma unroll
+        for (int m = 0; m < 3; m++) acc += K[a * 3 + m] * K[m * 3 + b];
+        Rl[a * 3 + b] = (a == b ? 1.0 : 0.0) + s * K[a * 3 + b] + c1 * acc;
+      }
+    double Rg[9], pg[3];
+    if (d == 0) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) Rg[i] = Rl[i];
+      pg[0] = j_rest[3 * j]; pg[1] = j_rest[3 * j + 1]; pg[2] = j_rest[3 * j + 2];
+    } else {
+      const double* sp = stack + (size_t)(d - 1) * 12 * SX_BLOCK + lane;
+      double Rp[9], pp[3];
+#pragma unroll
+      for (int i = 0; i < 9; i++) Rp[i] = sp[i * SX_BLOCK];
+#pragma unroll
+      for (int i = 0; i < 3; i++) pp[i] = sp[(9 + i) * SX_BLOCK];
+      const int pj = P.parent[k];
+      const double rel[3] = {j_rest[3 * j] - j_rest[3 * pj], j_rest[3 * j + 1] - j_rest[3 * pj + 1],
+                             j_rest[3 * j + 2] - j_rest[3 * pj + 2]};
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+          double acc = 0;
+#pragma unroll
+          for (int m = 0; m < 3; m++) acc += Rp[a * 3 + m] * Rl[m * 3 + b];
+          Rg[a * 3 + b] = acc;
+        }
+        pg[a] = pp[a] + Rp[a * 3] * rel[0] + Rp[a * 3 + 1] * rel[1] + Rp[a * 3 + 2] * rel[2];
+      }
+    }
+    double* so = stack + (size_t)d * 12 * SX_BLOCK + lane;
+#pragma unroll
+    for (int i = 0; i < 9; i++) so[i * SX_BLOCK] = Rg[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) so[(9 + i) * SX_BLOCK] = pg[i];
+    jo[3 * j] = (float)(pg[0] + tx);
+    jo[3 * j + 1] = (float)(pg[1] + ty);
+    jo[3 * j + 2] = (float)(pg[2] + tz);
+  }
+}
+
+// DFS program over the joints in `keep` (all when empty); rows from `row_of` (-1 = not written)
+static bool make_prog(int J, const int32_t* parents, const std::vector<char>& keep, const std::vector<int>& row_of,
+                      int nrow, SmplxProg* P) {
+  memset(P, 0, sizeof *P);
+  P->J = J;
+  P->nrow = nrow;
+  std::vector<std::vector<int>> kids(J);
+  int root = -1;
+  for (int j = 0; j < J; j++) {
+    if (parents[j] < 0) { if (root >= 0) return false; root = j; }
+    else kids[parents[j]].push_back(j);
+  }
+  if (root < 0) return false;
+  std::vector<std::pair<int, int>> st;     // (joint, depth)
+  st.push_back({root, 0});
+  int n = 0, md = 0;
+  while (!st.empty()) {
+    auto [j, d] = st.back();
+    st.pop_back();
+    if (!keep[j]) continue;
+    P->joint[n] = (short)j; P->depth[n] = (short)d; P->row[n] = (short)row_of[j];
+    P->parent[n] = (short)(parents[j] < 0 ? 0 : parents[j]);
+    n++;
+    md = std::max(md, d + 1);
+    for (int c = (int)kids[j].size() - 1; c >= 0; c--) st.push_back({kids[j][c], d + 1});
+  }
+  P->n = n;
+  P->max_depth = md;
+  return true;
+}
+
+}  // namespace gmr
+
+struct gmr_smplx {
+  int J = 0, nsel = 0;
+  gmr::SmplxProg all, sel;       // every joint (rows = joint index) / ancestor closure of the selection
+  double* d_jrest = nullptr;     // staging of the host entry points
+};
+
+extern "C" {
+
+int gmr_smplx_create(int J, const int32_t* parents, int nsel, const int32_t* sel, gmr_smplx_t** out) {
+  if (!parents || !out || J < 1 || J > SX_MAX_JOINTS) return gmr_fail(GMR_ERR_ARG, "gmr_smplx_create: 1 <= J <= %d", SX_MAX_JOINTS);
+  if (nsel < 0 || nsel > J || (nsel > 0 && !sel)) return gmr_fail(GMR_ERR_ARG, "gmr_smplx_create: bad selection");
+  for (int j = 0; j < J; j++)
+    if (parents[j] >= j || (j > 0 && parents[j] < 0) || (j == 0 && parents[j] >= 0))
+      return gmr_fail(GMR_ERR_ARG, "gmr_smplx_create: parents must precede children, joint 0 is the only root (joint %d)", j);
+  gmr_smplx* h = new (std::nothrow) gmr_smplx;
+  if (!h) return gmr_fail(GMR_ERR_ARG, "out of memory");
+  h->J = J;
+  h->nsel = nsel;
+  std::vector<char> keep(J, 1);
+  std::vector<int> row(J);
+  for (int j = 0; j < J; j++) row[j] = j;
+  bool ok = gmr::make_prog(J, parents, keep, row, J, &h->all);
+  if (ok && nsel > 0) {
+    std::fill(keep.begin(), keep.end(), 0);
+    std::fill(row.begin(), row.end(), -1);
+    for (int r = 0; r < nsel && ok; r++) {
+      int j = sel[r];
+      if (j < 0 || j >= J || row[j] >= 0) { ok = false; break; }
+      row[j] = r;
+      for (int a = j; a >= 0; a = parents[a]) keep[a] = 1;
+    }
+    ok = ok && gmr::make_prog(J, parents, keep, row, nsel, &h->sel);
+  } else if (ok) {
+    h->sel = h->all;
+  }
+  if (!ok) { delete h; return gmr_fail(GMR_ERR_ARG, "gmr_smplx_create: bad tree or duplicate / out-of-range selection"); }
+  const int lds_align = h->all.max_depth * 4 * SX_BLOCK * 8, lds_joints = h->all.max_depth * 12 * SX_BLOCK * 8;
+  if (lds_joints > 160 * 1024 - 1024) { delete h; return gmr_fail(GMR_ERR_ARG, "gmr_smplx_create: tree too deep (%d levels)", h->all.max_depth); }
+  hipError_t e = hipSuccess;
+  if (lds_align > 48 * 1024) {
+    e = hipFuncSetAttribute((const void*)gmr::smplx_align_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_align);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gmr::smplx_align_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_align);
+  }
+  if (e == hipSuccess && lds_joints > 48 * 1024)
+    e = hipFuncSetAttribute((const void*)gmr::smplx_joints_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_joints);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_jrest, (size_t)J * 3 * sizeof(double));
+  if (e != hipSuccess) { delete h; return gmr_fail(GMR_ERR_HIP, "gmr_smplx_create: %s", hipGetErrorString(e)); }
+  *out = h;
+  return GMR_OK;
+}
+
+int gmr_smplx_destroy(gmr_smplx_t* h) {
+  if (!h) return GMR_OK;
+  (void)hipFree(h->d_jrest);
+  delete h;
+  return GMR_OK;
+}
+
+int gmr_smplx_rows(const gmr_smplx_t* h) { return h ? h->sel.nrow : 0; }
+
+int gmr_smplx_joints_dev(gmr_smplx_t* h, int N, const double* d_j_rest, const float* d_full_pose, const float* d_transl,
+                         float* d_joints, void* stream) {
+  if (!h || N < 0 || !d_j_rest || !d_full_pose || !d_transl || !d_joints) return gmr_fail(GMR_ERR_ARG, "gmr_smplx_joints_dev: bad argument");
+  if (N == 0) return GMR_OK;
+  const int lds = h->all.max_depth * 12 * SX_BLOCK * 8;
+  hipLaunchKernelGGL(gmr::smplx_joints_kernel, dim3((N + SX_BLOCK - 1) / SX_BLOCK), dim3(SX_BLOCK), lds, (hipStream_t)stream,
+                     h->all, N, d_j_rest, d_full_pose, d_transl, d_joints);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return gmr_fail(GMR_ERR_HIP, "smplx_joints_kernel: %s", hipGetErrorString(e));
+  return GMR_OK;
+}
+
+int gmr_smplx_align_dev(gmr_smplx_t* h, int N, int jstride, const float* d_full_pose, const float* d_joints, int Nout,
+                        const double* d_target_time, double* d_out, void* stream) {
+  if (!h || N < 1 || Nout < 0 || jstride < h->J || !d_full_pose || !d_joints || !d_out)
+    return gmr_fail(GMR_ERR_ARG, "gmr_smplx_align_dev: bad argument");
+  if (!d_target_time && Nout != N) return gmr_fail(GMR_ERR_ARG, "gmr_smplx_align_dev: without target times Nout must equal N");
+  if (d_target_time && N < 2) return gmr_fail(GMR_ERR_ARG, "gmr_smplx_align_dev: fps alignment needs at least two source frames");
+  if (Nout == 0) return GMR_OK;
+  const gmr::SmplxProg& P = h->sel;
+  const int lds = P.max_depth * 4 * SX_BLOCK * 8;
+  dim3 grid((Nout + SX_BLOCK - 1) / SX_BLOCK), block(SX_BLOCK);
+  if (d_target_time)
+    hipLaunchKernelGGL(gmr::smplx_align_kernel<true>, grid, block, lds, (hipStream_t)stream, P, N, jstride, d_full_pose,
+                       d_joints, Nout, d_target_time, d_out);
+  else
+    hipLaunchKernelGGL(gmr::smplx_align_kernel<false>, grid, block, lds, (hipStream_t)stream, P, N, jstride, d_full_pose,
+                       d_joints, Nout, d_target_time, d_out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return gmr_fail(GMR_ERR_HIP, "smplx_align_kernel: %s", hipGetErrorString(e));
+  return GMR_OK;
+}
+
+// host-buffer variants: copy, launch, synchronise
+int gmr_smplx_joints(gmr_smplx_t* h, int N, const double* j_rest, const float* full_pose, const float* transl, float* joints) {
+  if (!h || N < 0 || !j_rest || !full_pose || !transl || !joints) return gmr_fail(GMR_ERR_ARG, "gmr_smplx_joints: bad argument");
+  if (N == 0) return GMR_OK;
+  const size_t nb_pose = (size_t)N * h->J * 3 * sizeof(float), nb_tr = (size_t)N * 3 * sizeof(float);
+  char* ws = nullptr;
+  hipError_t e = hipMalloc((void**)&ws, 2 * nb_pose + nb_tr + 64);
+  if (e != hipSuccess) return gmr_fail(GMR_ERR_HIP, "gmr_smplx_joints: %s", hipGetErrorString(e));
+  float* d_pose = (float*)ws;
+  float* d_j = (float*)(ws + nb_pose);
+  float* d_tr = (float*)(ws + 2 * nb_pose);
+  int rc = GMR_OK;
+  if ((e = hipMemcpy(h->d_jrest, j_rest, (size_t)h->J * 3 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(d_pose, full_pose, nb_pose, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(d_tr, transl, nb_tr, hipMemcpyHostToDevice)) != hipSuccess)
+    rc = gmr_fail(GMR_ERR_HIP, "gmr_smplx_joints: %s", hipGetErrorString(e));
+  if (rc == GMR_OK) rc = gmr_smplx_joints_dev(h, N, h->d_jrest, d_pose, d_tr, d_j, nullptr);
+  if (rc == GMR_OK && (e = hipMemcpy(joints, d_j, nb_pose, hipMemcpyDeviceToHost)) != hipSuccess)
+    rc = gmr_fail(GMR_ERR_HIP, "gmr_smplx_joints: %s", hipGetErrorString(e));
+  (void)hipFree(ws);
+  return rc;
+}
+
+int gmr_smplx_align(gmr_smplx_t* h, int N, int jstride, const float* full_pose, const float* joints, int Nout,
+                    const double* target_time, double* out) {
+  if (!h || N < 1 || Nout < 0 || jstride < (h ? h->J : 0) || !full_pose || !joints || !out)
+    return gmr_fail(GMR_ERR_ARG, "gmr_smplx_align: bad argument");
+  if (Nout == 0) return GMR_OK;
+  const size_t nb_pose = (size_t)N * h->J * 3 * sizeof(float), nb_j = (size_t)N * jstride * 3 * sizeof(float);
+  const size_t nb_t = (size_t)Nout * sizeof(double), nb_out = (size_t)Nout * h->sel.nrow * 7 * sizeof(double);
+  auto up = [](size_t v) { return (v + 63) / 64 * 64; };
+  char* ws = nullptr;
+  hipError_t e = hipMalloc((void**)&ws, up(nb_pose) + up(nb_j) + up(nb_t) + up(nb_out));
+  if (e != hipSuccess) return gmr_fail(GMR_ERR_HIP, "gmr_smplx_align: %s", hipGetErrorString(e));
+  float* d_pose = (float*)ws;
+  float* d_j = (float*)(ws + up(nb_pose));
+  double* d_t = (double*)(ws + up(nb_pose) + up(nb_j));
+  double* d_o = (double*)(ws + up(nb_pose) + up(nb_j) + up(nb_t));
+  int rc = GMR_OK;
+  if ((e = hipMemcpy(d_pose, full_pose, nb_pose, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(d_j, joints, nb_j, hipMemcpyHostToDevice)) != hipSuccess ||
+      (target_time && (e = hipMemcpy(d_t, target_time, nb_t, hipMemcpyHostToDevice)) != hipSuccess))
+    rc = gmr_fail(GMR_ERR_HIP, "gmr_smplx_align: %s", hipGetErrorString(e));
+  if (rc == GMR_OK) rc = gmr_smplx_align_dev(h, N, jstride, d_pose, d_j, Nout, target_time ? d_t : nullptr, d_o, nullptr);
+  if (rc == GMR_OK && (e = hipMemcpy(out, d_o, nb_out, hipMemcpyDeviceToHost)) != hipSuccess)
+    rc = gmr_fail(GMR_ERR_HIP, "gmr_smplx_align: %s", hipGetErrorString(e));
+  (void)hipFree(ws);
+  return rc;
+}
+
+}  // extern "C"

@@ -114,6 +114,33 @@ int gmr_fk_batch_dev(gmr_fk_t* fk, int B, const float* d_root_pos, const float* 
 int gmr_fk_batch(gmr_fk_t* fk, int B, const float* root_pos, const float* root_rot, const float* dof,
                  float* body_pos, float* body_rot, float* min_z);
 
+/* ---- N1: SMPL-X frame extraction (the step in front of the loop) ---------- */
+/* A kinematic tree of J <= 64 joints (parents[j] < j, joint 0 the root) and the joints whose poses are
+ * wanted: sel[nsel] (one output row each, in this order; nsel = 0 -> all J joints, row = joint).  For the
+ * retargeting loop sel lists the SMPL-X joints of the solver's packed human bodies, so that the output IS
+ * the `human` argument of gmr_retarget_streams. */
+typedef struct gmr_smplx gmr_smplx_t;
+int gmr_smplx_create(int J, const int32_t* parents, int nsel, const int32_t* sel, gmr_smplx_t** out);
+int gmr_smplx_destroy(gmr_smplx_t* h);
+int gmr_smplx_rows(const gmr_smplx_t* h);   /* rows per output frame (nsel, or J) */
+/* Replaces the joints of `body_model(betas, global_orient, body_pose, transl, ...)` as called at
+ * general_motion_retargeting/utils/smpl.py:12-34, without the mesh: joints f32[N][J][3] from the rest
+ * joints j_rest f64[J][3] (J_regressor applied to the shaped template, once per clip), the axis-angle
+ * poses full_pose f32[N][J][3] and transl f32[N][3].  (The body model is third-party: parity unpinned.) */
+int gmr_smplx_joints_dev(gmr_smplx_t* h, int N, const double* d_j_rest, const float* d_full_pose,
+                         const float* d_transl, float* d_joints, void* stream);
+int gmr_smplx_joints(gmr_smplx_t* h, int N, const double* j_rest, const float* full_pose, const float* transl,
+                     float* joints);
+/* Replaces get_smplx_data_offline_fast (utils/smpl.py:109-197) for one clip -- and get_smplx_data
+ * (:44-73) when target_time is NULL (then Nout == N, no interpolation):
+ *   full_pose f32[N][J][3], joints f32[N][jstride][3] (jstride >= J: the model appends landmark joints),
+ *   target_time f64[Nout] = np.linspace(0, N-1, Nout), Nout = N // int(src_fps / tgt_fps) (:120-127)
+ *   out f64[Nout][rows][7] = position xyz, global orientation quaternion wxyz per selected joint. */
+int gmr_smplx_align_dev(gmr_smplx_t* h, int N, int jstride, const float* d_full_pose, const float* d_joints,
+                        int Nout, const double* d_target_time, double* d_out, void* stream);
+int gmr_smplx_align(gmr_smplx_t* h, int N, int jstride, const float* full_pose, const float* joints, int Nout,
+                    const double* target_time, double* out);
+
 #ifdef __cplusplus
 }
 #endif

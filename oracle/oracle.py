@@ -18,8 +18,8 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "gmr_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("gmr_oracle.c", "gmr_oracle_smplx.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libgmr_oracle.so"])
     return _SO
 
@@ -171,3 +171,42 @@ def integrate(model, q, dq):
     q = _c(q, np.float64).copy()
     lib().orc_integrate(_p(model), _p(q), _p(_c(dq, np.float64)))
     return q
+
+
+# ---- N1: SMPL-X frame extraction (gmr_oracle_smplx.c) ------------------------------------------------
+def smplx_slerp(q1_xyzw, q2_xyzw, t):
+    out = np.empty(4)
+    lib().orc_smplx_slerp(_p(_c(q1_xyzw, np.float64)), _p(_c(q2_xyzw, np.float64)), C.c_double(float(t)), _p(out))
+    return out
+
+
+def smplx_align(parents, full_pose, joints, target_time=None, sel=None):
+    """full_pose f32[N, J, 3], joints f32[N, >=J, 3] -> f64[Nout, nsel, 7] (pos, quat wxyz)."""
+    parents = _c(parents, np.int32)
+    J = len(parents)
+    full_pose = _c(full_pose, np.float32).reshape(-1, J, 3)
+    joints = _c(joints, np.float32)
+    N = full_pose.shape[0]
+    tt = None if target_time is None else _c(target_time, np.float64)
+    nout = N if tt is None else len(tt)
+    s = None if sel is None else _c(sel, np.int32)
+    nrow = J if s is None else len(s)
+    out = np.empty((nout, nrow, 7))
+    rc = lib().orc_smplx_align(N, J, joints.shape[1], _p(parents), _p(full_pose), _p(joints), nout,
+                               None if tt is None else _p(tt), nrow, None if s is None else _p(s), _p(out))
+    if rc:
+        raise ValueError("orc_smplx_align: bad arguments")
+    return out
+
+
+def smplx_joints(parents, j_rest, full_pose, transl):
+    parents = _c(parents, np.int32)
+    J = len(parents)
+    full_pose = _c(full_pose, np.float32).reshape(-1, J, 3)
+    transl = _c(transl, np.float32)
+    out = np.empty((full_pose.shape[0], J, 3), np.float32)
+    rc = lib().orc_smplx_joints(full_pose.shape[0], J, _p(parents), _p(_c(j_rest, np.float64)), _p(full_pose),
+                                _p(transl), _p(out))
+    if rc:
+        raise ValueError("orc_smplx_joints: bad arguments")
+    return out

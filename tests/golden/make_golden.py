@@ -16,6 +16,13 @@ is importable in the build container:
   only) on ``tests/golden/synthetic.bvh`` (a 22-joint, 12-frame BVH authored by this repository).
   This pins the "next" row N2.
 
+* G-SMPLX -- the reference's SMPL-X frame extraction (``utils/smpl.py:44-197``: ``get_smplx_data``, ``slerp``,
+  ``get_smplx_data_offline_fast`` -- NumPy/SciPy arithmetic) on a synthetic ``smplx_output`` (seeded random
+  ``joints`` / ``full_pose`` float32 tensors, a 55-joint parent table) for 120->30, 60->30, 50->30 fps and the
+  no-alignment branch.  The ``smplx`` package is not installed and its body model is not needed by these
+  functions; a placeholder module supplies only ``JOINT_NAMES`` as 55 opaque labels ("j00".."j54") that become
+  the dict keys.  This pins the pose half of the "next" row N1 (the body-model half stays unpinned).
+
 Nothing here pins rows H4-H7 (the mink/MuJoCo/DAQP numerics): "parity unpinned", see DESIGN.md.
 
 Only numbers and names are stored (``np.savez_compressed``; loadable with allow_pickle=False).
@@ -200,7 +207,70 @@ def make_bvh():
     print("g_bvh.npz:", arr.shape)
 
 
+def make_smplx():
+    """G-SMPLX: reference utils/smpl.py on synthetic body-model outputs (see the module docstring)."""
+    import torch
+    smplx = types.ModuleType("smplx")
+    jn = types.ModuleType("smplx.joint_names")
+    jn.JOINT_NAMES = [f"j{i:02d}" for i in range(60)]         # opaque labels; only the first len(parents) are used
+    smplx.joint_names = jn
+    sys.modules["smplx"], sys.modules["smplx.joint_names"] = smplx, jn
+    smpl = _load_ref_module("utils.smpl")
+    # a 55-joint tree with the branching of a humanoid + two 15-joint hands (parents precede children)
+    parents = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 15, 15, 15]
+                       + [20, 25, 26, 20, 28, 29, 20, 31, 32, 20, 34, 35, 20, 37, 38]
+                       + [21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50, 21, 52, 53], dtype=np.int64)
+    J = len(parents)
+    out = {"parents": parents}
+    body_model = types.SimpleNamespace(parents=parents)
+    for case, (src_fps, N, tgt_fps) in enumerate(((120.0, 41, 30), (60.0, 23, 30), (50.0, 17, 30), (30.0, 9, 30),
+                                                  (120.0, 8, 30))):
+        rng = np.random.default_rng(7000 + case)
+        # smooth random-walk poses with a few large rotations (angles up to ~pi) and sign flips across frames
+        base = rng.normal(0, 0.8, size=(1, J, 3))
+        walk = np.cumsum(rng.normal(0, 0.15, size=(N, J, 3)), axis=0)
+        pose = base + walk
+        pose[:, 5] *= 2.2                                   # one joint sweeps through large angles
+        pose[N // 2:, 7] *= -1.0                            # one joint jumps to the antipodal side mid-clip
+        pose[:, 9] *= 1e-5                                  # one joint stays in the small-angle branch
+        pose[:, 11] = pose[0, 11]                           # one joint is constant (lerp branch of slerp)
+        full_pose = torch.tensor(pose.reshape(N, J * 3), dtype=torch.float32)
+        joints = torch.tensor(np.cumsum(rng.normal(0, 0.02, size=(N, J + 3, 3)), axis=0) + rng.normal(0, 0.5, size=(1, J + 3, 3)),
+                              dtype=torch.float32)          # the model returns extra landmark joints after the 55
+        so = types.SimpleNamespace(global_orient=full_pose[:, :3].clone(), full_pose=full_pose, joints=joints)
+        data = {"mocap_frame_rate": np.array(src_fps), "pose_body": np.zeros((N, 63))}
+        frames, aligned_fps = smpl.get_smplx_data_offline_fast(data, body_model, so, tgt_fps=tgt_fps)
+        names = jn.JOINT_NAMES[:J]
+        arr = np.array([[np.concatenate([np.asarray(f[n][0], dtype=np.float64), f[n][1]]) for n in names] for f in frames])
+        tag = f"c{case}"
+        out[f"{tag}__src_fps"] = np.array(src_fps)
+        out[f"{tag}__tgt_fps"] = np.array(tgt_fps)
+        out[f"{tag}__full_pose"] = full_pose.numpy()
+        out[f"{tag}__joints"] = joints.numpy()
+        out[f"{tag}__frames"] = arr                          # [N', 55, 7] pos xyz + quat wxyz
+        out[f"{tag}__aligned_fps"] = np.array(float(aligned_fps))
+        # the per-frame entry point on the source frames (no alignment)
+        single = [smpl.get_smplx_data(data, body_model, so, t) for t in (0, N - 1)]
+        out[f"{tag}__single"] = np.array([[np.concatenate([np.asarray(f[n][0], dtype=np.float64), f[n][1]]) for n in names]
+                                          for f in single])
+    # slerp() itself on a few hand-picked pairs
+    from scipy.spatial.transform import Rotation as R
+    rng = np.random.default_rng(7100)
+    q1 = rng.normal(size=(12, 4)); q2 = rng.normal(size=(12, 4))
+    q2[:3] = q1[:3] + 1e-3 * rng.normal(size=(3, 4))        # nearly equal -> lerp branch
+    q2[3:5] = -q1[3:5] + 1e-2 * rng.normal(size=(2, 4))     # nearly antipodal -> flipped
+    tt = rng.uniform(0, 1, size=12)
+    res = np.array([smpl.slerp(R.from_quat(a), R.from_quat(b), t).as_quat() for a, b, t in zip(q1, q2, tt)])
+    out["slerp__q1"], out["slerp__q2"], out["slerp__t"], out["slerp__out"] = q1, q2, tt, res
+    np.savez_compressed(OUT / "g_smplx.npz", **out)
+    print("g_smplx.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "smplx":
+        make_smplx()
+        sys.exit(0)
     make_pre()
     make_fk()
     make_bvh()
+    make_smplx()
