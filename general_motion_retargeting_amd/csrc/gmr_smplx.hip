@@ -13,7 +13,7 @@
 // orders of magnitude above the IK kernel's frame rate, so they are written for exactness, not tuned.
 //
 // Arithmetic follows the SciPy formulas the reference goes through (from_rotvec / as_rotvec small-angle
-// series at 1e-3, from_quat normalisation, interp1d's float32 difference); see oracle/gmr_oracle_smplx.c.
+// series at 1e-3, from_quat normalisation, interp1d's float32 difference).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
