@@ -119,3 +119,53 @@ def retarget_bvh_files(bvh_files: Sequence[str], tgt_robot: str, fps: float = 30
     clips = [load_lafan1_packed(f, gmr.human_body_names)[0] for f in bvh_files]
     return retarget_clips("bvh", tgt_robot, clips, [fps] * len(clips), actual_human_height=1.75,
                           height_adjust=height_adjust, root_origin_offset=root_origin_offset)
+
+
+def retarget_smplx_files(smplx_files: Sequence[str], smplx_body_model_path: str, tgt_robot: str, tgt_fps: int = 30,
+                         height_adjust: bool = True, root_origin_offset: bool = True,
+                         skip_errors: bool = True) -> List[Optional[Dict]]:
+    """``scripts/smplx_to_robot_dataset.py:39-146`` (``process_file``) for a list of AMASS-style SMPL-X
+    files, everything after the file read on the device: joints-only body model + fps alignment
+    (utils/smpl.py) -> packed frames -> IK -> FK post-processing.  A file's human height comes from its betas
+    (smpl.py:36-39), so files are grouped by height: one task set and ONE ragged IK launch per group, the
+    groups running concurrently on separate HIP streams.  Both adjustments default to on like that script.
+    Returns one motion dict per file in input order (``None`` for a file that failed to load when
+    ``skip_errors`` -- the script prints and skips, :62-76)."""
+    from .utils import smpl
+    loaded: Dict[int, tuple] = {}
+    for i, f in enumerate(smplx_files):
+        try:
+            loaded[i] = smpl.load_smplx_file(f, smplx_body_model_path)
+        except Exception as e:  # noqa: BLE001 - mirrors the script's print-and-skip
+            if not skip_errors:
+                raise
+            print(f"Error loading {f}: {e}")
+    by_height: Dict[float, List[int]] = {}
+    for i, (_, _, _, h) in loaded.items():
+        by_height.setdefault(float(h), []).append(i)
+    groups, members, fps_of = [], [], {}
+    for h, idxs in by_height.items():
+        gmr = GeneralMotionRetargeting("smplx", tgt_robot, actual_human_height=h)
+        clips = []
+        for i in idxs:
+            data, bm, so, _ = loaded[i]
+            packed, fps_of[i] = smpl.smplx_frames_packed(gmr, data, bm, so, tgt_fps=tgt_fps)
+            clips.append(packed)
+        lens = np.array([c.shape[0] for c in clips], dtype=np.int32)
+        T = max(int(lens.max()), 1)
+        human = np.zeros((len(clips), T, len(gmr.human_body_names), 7))
+        human[..., 3] = 1.0
+        for k, c in enumerate(clips):
+            human[k, : c.shape[0]] = c
+        groups.append({"src_human": "smplx", "tgt_robot": tgt_robot, "actual_human_height": h, "human": human, "lens": lens})
+        members.append((idxs, lens, gmr.xml_file))
+    results = retarget_mixed(groups) if groups else []
+    out: List[Optional[Dict]] = [None] * len(smplx_files)
+    km = None
+    for (idxs, lens, xml), (qpos, _, status) in zip(members, results):
+        if (status != 0).any():
+            raise RuntimeError(f"IK failed for files {[smplx_files[idxs[k]] for k in np.nonzero(status)[0]]}")
+        km = km or KinematicsModel(xml)
+        for k, i in enumerate(idxs):
+            out[i] = postprocess_clip(qpos[k, : lens[k]], km, fps_of[i], height_adjust, root_origin_offset)
+    return out

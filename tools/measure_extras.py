@@ -81,4 +81,45 @@ for want_rot in (True, False):
     ms = float(np.median(ms))
     byt = B * (116 + 12 + 16 + 456 + (608 if want_rot else 0))
     out["fk_batch_1M_" + ("pos_rot" if want_rot else "pos")] = {"ms": ms, "GBps": byt / ms / 1e6, "frames_per_s": B / ms * 1e3}
+# 5. N1: SMPL-X frame extraction kernels (120 -> 30 fps alignment of 2^20 source frames; joints-only body model)
+from general_motion_retargeting_amd.utils import smpl  # noqa: E402
+N = 1 << 20
+par = smpl.SMPLX_PARENTS
+pose = (rng.normal(0, 0.5, size=(1, 55, 3)) + 0.05 * rng.normal(size=(N, 55, 3))).astype(np.float32)
+jts = rng.normal(size=(N, 55, 3)).astype(np.float32)
+tt = np.linspace(0, N - 1, N // 4)
+names = list(smpl.SMPLX_JOINT_NAMES)
+sel = [names.index(n) for n in g.human_body_names]
+closure = set()
+for j in sel:
+    while j >= 0:
+        closure.add(j); j = int(par[j])
+d_pose = _lib.DeviceBuffer.from_host(pose); d_j = _lib.DeviceBuffer.from_host(jts); d_tt = _lib.DeviceBuffer.from_host(tt)
+for tag, s in (("packed_rows", sel), ("all_55_joints", None)):
+    hs = _lib.SmplxHandle(par, s)
+    nrow = hs.rows
+    d_o = _lib.DeviceBuffer(len(tt) * nrow * 56)
+    hs.align_dev(N, 55, d_pose, d_j, len(tt), d_tt, d_o)
+    _lib.check(L.gmr_stream_sync(None))
+    ms = []
+    for _ in range(5):
+        a, b = _lib.Event(), _lib.Event()
+        a.record(); hs.align_dev(N, 55, d_pose, d_j, len(tt), d_tt, d_o); b.record()
+        ms.append(a.elapsed_ms(b))
+    ms = float(np.median(ms))
+    nj = len(closure) if s is not None else 55
+    byt = len(tt) * (2 * 12 * nj + 2 * 12 * nrow + 8 + 56 * nrow)
+    out["smplx_align_" + tag] = {"ms": ms, "out_frames_per_s": len(tt) / ms * 1e3, "algorithmic_GBps": byt / ms / 1e6,
+                                 "bytes_per_out_frame": byt // len(tt), "rows": nrow}
+hs = _lib.SmplxHandle(par)
+d_jr = _lib.DeviceBuffer.from_host(rng.normal(size=(55, 3))); d_tr = _lib.DeviceBuffer.from_host(rng.normal(size=(N, 3)).astype(np.float32))
+hs.joints_dev(N, d_jr, d_pose, d_tr, d_j)
+_lib.check(L.gmr_stream_sync(None))
+ms = []
+for _ in range(5):
+    a, b = _lib.Event(), _lib.Event()
+    a.record(); hs.joints_dev(N, d_jr, d_pose, d_tr, d_j); b.record()
+    ms.append(a.elapsed_ms(b))
+ms = float(np.median(ms))
+out["smplx_joints_1M"] = {"ms": ms, "frames_per_s": N / ms * 1e3, "algorithmic_GBps": N * (660 + 12 + 660) / ms / 1e6}
 print(json.dumps(out, indent=1))
