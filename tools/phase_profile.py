@@ -27,7 +27,7 @@ def main():
     pkg = os.path.join(ROOT, "general_motion_retargeting_amd")
     so = os.path.join(pkg, "libgmrhip_prof.so")
     if not os.path.exists(so) or os.environ.get("REBUILD"):
-        srcs = [os.path.join(pkg, "csrc", f) for f in ("gmr_ik.hip", "gmr_fk.hip", "gmr_abi.hip")]
+        srcs = [os.path.join(pkg, "csrc", f) for f in ("gmr_ik.hip", "gmr_fk.hip", "gmr_smplx.hip", "gmr_abi.hip")]
         subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
                                "-DGMR_IK_PROFILE", "-o", so] + srcs)
     _lib.LIB_PATH = so
