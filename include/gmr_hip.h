@@ -8,7 +8,9 @@
  * (gmr_last_error() returns a thread-local message); handles are immutable after creation, so
  * batch calls on different HIP streams are re-entrant.  "dev" entry points take device pointers
  * and a hipStream_t (as void*; NULL = the default stream) and never synchronise; the entry points
- * without the suffix take host pointers, copy, launch and synchronise.
+ * without the suffix take host pointers, copy, launch and synchronise; they stage through a per-handle
+ * device workspace, so at most one host-pointer call per handle at a time (like the reference object,
+ * which is not thread-safe either: SURVEY.md section 8b).
  *
  * Row IDs (H1..H10) refer to SURVEY.md section 8(a).
  */
