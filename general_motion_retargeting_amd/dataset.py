@@ -169,3 +169,15 @@ def retarget_smplx_files(smplx_files: Sequence[str], smplx_body_model_path: str,
         for k, i in enumerate(idxs):
             out[i] = postprocess_clip(qpos[k, : lens[k]], km, fps_of[i], height_adjust, root_origin_offset)
     return out
+
+
+def retarget_single_clip(retargeter: GeneralMotionRetargeting, frames: Sequence, fps: float,
+                         skip_first_frame: bool = True) -> Dict:
+    """The save path of the single-clip scripts (``scripts/smplx_to_robot.py:104-161``,
+    ``scripts/bvh_to_robot.py`` alike): one ``retarget()`` per displayed frame, then a pkl dict with
+    ``root_rot`` xyzw, ``local_body_pos = None`` and ``link_body_list = None`` (:146-158).  Their loop
+    increments the index BEFORE the first use (:104-111), so frame 0 is never retargeted; that is the default
+    here too.  One launch instead of one call per frame; continues from ``retargeter``'s configuration."""
+    seq = frames[1:] if skip_first_frame else frames
+    qpos = retargeter.retarget_clip(seq)
+    return motion_dict(fps, qpos[:, :3].copy(), qpos[:, [4, 5, 6, 3]].copy(), qpos[:, 7:].copy(), None, None)

@@ -423,3 +423,27 @@ def test_generic_topologies(hip, oracle, tmp_path, topology):
         assert np.array_equal(ns_h, ns_o), (topology, waves)
         joint, pos, rot = _compare(q_h, q_o)
         assert joint <= 1e-8 and pos <= 1e-8 and rot <= 1e-8, (topology, waves, joint, pos, rot)
+
+
+@pytest.mark.gpu
+def test_single_clip_script_contract(tmp_path):
+    """one synthetic stream S=1, T=300 through the equivalent of
+    scripts/smplx_to_robot.py:104-161 -- frame 0 skipped by the script's loop, pkl with root_rot xyzw and
+    local_body_pos / link_body_list None, readable by load_robot_motion."""
+    from general_motion_retargeting_amd import GeneralMotionRetargeting, dataset, load_robot_motion, save_robot_motion, synth
+    g = GeneralMotionRetargeting("smplx", "unitree_g1", actual_human_height=1.7)
+    human, _ = synth.make_streams(g.model, g._tables, 1, 300, seed=21)
+    frames = synth.streams_to_dicts(g._tables, human[0])
+    md = dataset.retarget_single_clip(g, frames, fps=30.0)
+    assert list(md) == ["fps", "root_pos", "root_rot", "dof_pos", "local_body_pos", "link_body_list"]
+    assert md["root_pos"].shape == (299, 3) and md["root_rot"].shape == (299, 4) and md["dof_pos"].shape == (299, 29)
+    assert md["local_body_pos"] is None and md["link_body_list"] is None
+    g2 = GeneralMotionRetargeting("smplx", "unitree_g1", actual_human_height=1.7)
+    q = np.array([g2.retarget(f) for f in frames[1:6]])                    # the script's loop, first five calls
+    assert np.abs(md["root_pos"][:5] - q[:, :3]).max() < 1e-12
+    assert np.abs(md["root_rot"][:5] - q[:, [4, 5, 6, 3]]).max() < 1e-12
+    assert np.abs(md["dof_pos"][:5] - q[:, 7:]).max() < 1e-12
+    p = str(tmp_path / "clip.pkl")
+    save_robot_motion(p, md)
+    data, fps, rp, rr, dp, lbp, names = load_robot_motion(p)
+    assert fps == 30.0 and lbp is None and names is None and np.array_equal(rr[:, [1, 2, 3, 0]], md["root_rot"])
