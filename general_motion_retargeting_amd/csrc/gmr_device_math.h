@@ -133,46 +133,8 @@ __device__ __forceinline__ void se3_log_rel(d3 pb, d4 qb, d3 pt, d4 qt, double e
   e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = w.x; e[4] = w.y; e[5] = w.z;
 }
 
-// Jl^-1(e) = [[A, B], [0, A]], B = -A Q A (Barfoot 7.86b); identity when |w|^2 < 1e-10 (mink)
-__device__ __forceinline__ void se3_jlinv(const double e[6], m3& A, m3& B) {
-  d3 rho = {e[0], e[1], e[2]}, w = {e[3], e[4], e[5]};
-  double t2 = dot(w, w);
-#pragma unroll
-  for (int i = 0; i < 9; i++) { A.a[i] = 0.0; B.a[i] = 0.0; }
-  A.a[0] = A.a[4] = A.a[8] = 1.0;
-  if (t2 < 1e-10) return;
-  double a = vinv_coef(t2);
-  m3 W = skew(w), V = skew(rho);
-  m3 W2 = mmul(W, W);
-#pragma unroll
-  for (int i = 0; i < 9; i++) A.a[i] += -0.5 * W.a[i] + a * W2.a[i];
-  double c1, c2, c3;
-  if (t2 < 1e-2) {
-    c1 = 1.0 / 6.0 - t2 / 120.0 + t2 * t2 / 5040.0 - t2 * t2 * t2 / 362880.0;
-    c2 = -1.0 / 24.0 + t2 / 720.0 - t2 * t2 / 40320.0 + t2 * t2 * t2 / 3628800.0;
-    c3 = -1.0 / 120.0 + t2 / 5040.0 - t2 * t2 / 362880.0 + t2 * t2 * t2 / 39916800.0;
-  } else {
-    double t = sqrt(t2), s, c;
-    sincos(t, &s, &c);
-    c1 = (t - s) / (t2 * t);
-    c2 = (1.0 - 0.5 * t2 - c) / (t2 * t2);
-    c3 = (t - s - t2 * t / 6.0) / (t2 * t2 * t);
-  }
-  double c4 = -0.5 * (c2 - 3.0 * c3);
-  m3 WV = mmul(W, V), VW = mmul(V, W);
-  m3 WVW = mmul(WV, W), WWV = mmul(W, WV), VWW = mmul(VW, W);
-  m3 WVWW = mmul(WVW, W), WWVW = mmul(W, WVW);
-  m3 Q;
-#pragma unroll
-  for (int i = 0; i < 9; i++)
-    Q.a[i] = 0.5 * V.a[i] + c1 * (WV.a[i] + VW.a[i] + WVW.a[i]) - c2 * (WWV.a[i] + VWW.a[i] - 3.0 * WVW.a[i]) +
-             c4 * (WVWW.a[i] + WWVW.a[i]);
-  m3 AQA = mmul(mmul(A, Q), A);
-#pragma unroll
-  for (int i = 0; i < 9; i++) B.a[i] = -AQA.a[i];
-}
-
-// The same Jl^-1(e) with the skew products of Q collapsed by [a]x[b]x = b a^T - (a.b) I
+// Jl^-1(e) = [[A, B], [0, A]], B = -A Q A (Barfoot 7.86b; identity when |w|^2 < 1e-10, mink) with the
+// skew products of Q collapsed by [a]x[b]x = b a^T - (a.b) I
 // (s = w.rho, n = w x rho, m = w x n):
 //   Q = 1/2 [rho]x + c1 (rho w^T + w rho^T) - 2 c1 s I - (c1 + c2) s [w]x - c2 [m]x - 2 c4 s (w w^T - t^2 I)
 //   A = (1 - a t^2) I - 1/2 [w]x + a w w^T
