@@ -67,7 +67,10 @@ def main():
     dist = None
     torch = None
     backend = os.environ.get("GMR_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 path on one GPU
-    if world > 1:
+    # GMR_BENCH_FORCE_DIST=1 under torch.distributed.run with ONE rank walks the whole RCCL path
+    # (init, broadcast, barrier, all-reduce) on a one-GPU box
+    use_dist = world > 1 or (os.environ.get("GMR_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         import torch  # plumbing only: rendezvous, RCCL broadcast, barrier
         import torch.distributed as dist
         if backend == "nccl":
@@ -86,7 +89,7 @@ def main():
         blob = np.concatenate([mb.view(np.uint8).ravel(), ts.view(np.uint8).ravel()])
     else:
         blob = np.zeros(nbytes, dtype=np.uint8)
-    if world > 1:
+    if use_dist:
         t = torch.from_numpy(blob).to(comm_dev)
         dist.broadcast(t, src=0)          # RCCL over xGMI, ~24 KB, once
         blob = t.cpu().numpy()
@@ -109,7 +112,7 @@ def main():
 
     def sync_all():
         _lib.check(L.gmr_stream_sync(None))
-        if world > 1:
+        if use_dist:
             if backend == "nccl":
                 torch.cuda.synchronize()
             dist.barrier()
@@ -134,7 +137,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = [a.elapsed_ms(b) for a, b in evs]
 
-    if world > 1:
+    if use_dist:
         tt_ = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
         elapsed = float(tt_.item())
@@ -233,7 +236,7 @@ def main():
             out["frames_with_different_solve_count"] = int((ns_hip != ns_cpu).any(axis=-1).sum())
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

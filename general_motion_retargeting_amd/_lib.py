@@ -3,7 +3,9 @@ missing or no GPU is visible the product path raises -- there is deliberately no
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -69,6 +71,37 @@ _SIGS = {
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
 
+HIP_RUNTIME = None   # path of the HIP runtime preloaded by _share_hip_runtime(), if any
+
+
+def _share_hip_runtime():
+    """One HIP runtime per process.  A PyTorch-ROCm wheel bundles its own ``libamdhip64.so`` +
+    ``libhsa-runtime64.so`` and asks the loader for them by their unversioned names, so when libgmrhip.so has
+    already pulled in the system runtime (``/opt/rocm``, by SONAME ``libamdhip64.so.7``) a later ``import
+    torch`` loads a SECOND runtime and finds "No HIP GPUs" (the first one owns the device).  The other order
+    works (our SONAME request matches torch's copy).  So: if torch is installed but not yet imported, load ITS
+    runtime first -- without importing torch -- and let libgmrhip.so bind to it.
+    ``GMR_HIP_RUNTIME=system`` keeps the system runtime, ``GMR_HIP_RUNTIME=/path/libamdhip64.so`` picks one."""
+    global HIP_RUNTIME
+    mode = os.environ.get("GMR_HIP_RUNTIME", "auto")
+    if mode == "system" or "torch" in sys.modules:
+        return
+    path = mode if mode not in ("auto", "torch") else None
+    if path is None:
+        try:
+            spec = importlib.util.find_spec("torch")
+        except (ImportError, ValueError):
+            spec = None
+        for d in (spec.submodule_search_locations or []) if spec else []:
+            cand = os.path.join(d, "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                path = cand
+                break
+    if path:
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+        HIP_RUNTIME = path
+
+
 def lib():
     """Load libgmrhip.so (raises GmrHipError when it has not been built)."""
     global _lib
@@ -77,6 +110,7 @@ def lib():
             raise GmrHipError(
                 f"{LIB_PATH} not found: build it with `python -m general_motion_retargeting_amd.build` "
                 "(there is no CPU fallback in the product path)")
+        _share_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)

@@ -1,4 +1,5 @@
 """-m gpu: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs."""
+import os
 import numpy as np
 import pytest
 
@@ -447,3 +448,29 @@ def test_single_clip_script_contract(tmp_path):
     save_robot_motion(p, md)
     data, fps, rp, rr, dp, lbp, names = load_robot_motion(p)
     assert fps == 30.0 and lbp is None and names is None and np.array_equal(rr[:, [1, 2, 3, 0]], md["root_rot"])
+
+
+@pytest.mark.gpu
+def test_library_and_torch_share_one_hip_runtime():
+    """bench.py --gpus N loads libgmrhip.so BEFORE it imports torch for the RCCL plumbing.  A PyTorch-ROCm wheel
+    bundles its own HIP runtime; two runtimes in one process leave the second without a device ("No HIP GPUs are
+    available").  _lib._share_hip_runtime() makes both bind to one: checked in a fresh process, library first."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys\n"
+        "from general_motion_retargeting_amd import _lib\n"
+        "L = _lib.lib(); _lib.require_gpu(); assert L.gmr_set_device(0) == 0\n"
+        "b = _lib.DeviceBuffer(1 << 20)\n"
+        "import torch\n"
+        "assert torch.cuda.is_available() and torch.cuda.device_count() >= 1\n"
+        "x = torch.arange(8, device='cuda:0', dtype=torch.float32)\n"
+        "assert float((x * 2).sum().item()) == 56.0\n"
+        "maps = open('/proc/self/maps').read()\n"
+        "libs = {l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l}\n"
+        "assert len(libs) == 1, libs\n"
+        "print('one runtime:', libs.pop())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "one runtime:" in r.stdout
