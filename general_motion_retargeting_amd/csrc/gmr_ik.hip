@@ -240,8 +240,9 @@ __device__ __forceinline__ void pairs_phase(const IkLayout& L, double* sm, int s
   double* cpart = sm + L.cpart;
   const double* X = sm + L.xa;
   for (int p = vlane; p < P; p += nvl) {
-    int k = tb.pair_task[p], dof = tb.pair_dof[p];
-    int b = tb.task_body[k];
+    const unsigned info = (unsigned short)tb.pair_task[p];       // [3:0] task, [9:4] dof, [15:10] task body
+    const int k = info & 15u, dof = (info >> 4) & 63u, b = info >> 10;
+    const int c = tb.pair_dof[p];                                  // body of hinge dof - 6 (0 for the base)
     d3 pb = {X[7 * b], X[7 * b + 1], X[7 * b + 2]};
     d4 qb = {X[7 * b + 3], X[7 * b + 4], X[7 * b + 5], X[7 * b + 6]};
     d3 lin, ang;
@@ -254,7 +255,6 @@ __device__ __forceinline__ void pairs_phase(const IkLayout& L, double* sm, int s
       ang = qrot(q0, d3{a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0});
       lin = cross(ang, pb - d3{X[0], X[1], X[2]});
     } else {
-      int c = hinge_body[dof - 6];
       const double* xa = sm + L.xaxis + 3 * c;
       ang = d3{xa[0], xa[1], xa[2]};
       lin = cross(ang, pb - d3{X[7 * c], X[7 * c + 1], X[7 * c + 2]});

@@ -359,9 +359,12 @@ inline std::vector<char> make_ik_image(const gmr_model_t& m, const gmr_taskset_t
       sm[L.wrot[s] + k] = ts.w_rot[s][k];
       for (int d = 0; d < nv; d++) si[L.i_pair_index[s] + k * nv + d] = (short)ts.pair_index[s][k][d];
     }
+    // per (task, dof) pair, everything the Jacobian-column phase looks up, packed so that it is two
+    // independent 16-bit reads instead of a chain of four: [3:0] task, [9:4] dof, [15:10] task body; hinge body
     for (int p = 0; p < L.P[s]; p++) {
-      si[L.i_pair_task[s] + p] = (short)ts.pair_task[s][p];
-      si[L.i_pair_dof[s] + p] = (short)ts.pair_dof[s][p];
+      const int k = ts.pair_task[s][p], d = ts.pair_dof[s][p];
+      si[L.i_pair_task[s] + p] = (short)(unsigned short)(k | (d << 4) | (ts.task_body[s][k] << 10));
+      si[L.i_pair_dof[s] + p] = (short)(d >= 6 ? m.hinge_body[d - 6] : 0);
     }
   }
   return img;
