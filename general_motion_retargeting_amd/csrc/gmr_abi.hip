@@ -380,6 +380,7 @@ int gmr_fk_create(int nbody, const int32_t* parent, const float* local_t, const 
     t.nslot = ns > 0 ? ns : 1;
     t.load_slot[0] = -1;
     for (int b = 1; b < nbody; b++) t.load_slot[b] = (short)(parent[b] == b - 1 ? -1 : t.save_slot[parent[b]]);
+    for (int b = 0; b < nbody; b++) t.parent[b] = (short)(b == 0 ? 0 : parent[b]);
   }
   for (int b = 0; b < nbody; b++) {
     if (dof_idx[b] >= ndof) { delete k; return fail(GMR_ERR_ARG, "dof_idx[%d] out of range", b); }

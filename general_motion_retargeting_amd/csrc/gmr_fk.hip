@@ -62,16 +62,20 @@ __global__ __launch_bounds__(FK_BLOCK) void fk_batch_kernel(const FkTree* __rest
                                                             float* __restrict__ body_pos,
                                                             float* __restrict__ body_rot,
                                                             float* __restrict__ min_part) {
-  extern __shared__ __align__(16) float fsm[];  // slots [nslot][7][FK_BLOCK], then (STAGED) pos [FK_BLOCK][nb*3], rot [FK_BLOCK][nb*4]
+  // slots [nslot][SW][FK_BLOCK], then (STAGED) pos [FK_BLOCK][nb*3], rot [FK_BLOCK][nb*4].  A parked parent needs
+  // SW = 7 floats (pos, rot) when results go straight to memory; when they are staged, the parent's position is
+  // simply re-read from the staging area and only the rotation is parked (conflict-free columns): SW = 4
+  extern __shared__ __align__(16) float fsm[];
   __shared__ float red[FK_BLOCK / 64];
   const int nb = tree->nbody, ndof = tree->ndof;
   const int tid = threadIdx.x;
   const long long f = (long long)blockIdx.x * FK_BLOCK + tid;
   const bool on = f < B;
   const long long fc = on ? f : 0;
+  const int SW = STAGED ? 4 : 7;
   float* stk = fsm + tid;
   const int row = nb * 3;
-  float* outb = fsm + tree->nslot * 7 * FK_BLOCK;  // used when STAGED
+  float* outb = fsm + tree->nslot * SW * FK_BLOCK;  // used when STAGED
   float* outr = outb + FK_BLOCK * row;             // used when STAGED and body_rot
   const int rrow = nb * 4;
   float zmin = INFINITY;
@@ -81,10 +85,10 @@ __global__ __launch_bounds__(FK_BLOCK) void fk_batch_kernel(const FkTree* __rest
     float px = root_pos[fc * 3], py = root_pos[fc * 3 + 1], pz = root_pos[fc * 3 + 2];
     f4 rot = {root_rot[fc * 4], root_rot[fc * 4 + 1], root_rot[fc * 4 + 2], root_rot[fc * 4 + 3]};
     cpx = px; cpy = py; cpz = pz; crot = rot;
-    if (tree->save_slot[0] >= 0) {
-      float* sl = stk + tree->save_slot[0] * 7 * FK_BLOCK;
-      sl[0] = px; sl[FK_BLOCK] = py; sl[2 * FK_BLOCK] = pz;
-      sl[3 * FK_BLOCK] = rot.x; sl[4 * FK_BLOCK] = rot.y; sl[5 * FK_BLOCK] = rot.z; sl[6 * FK_BLOCK] = rot.w;
+    if (tree->save_slot[0] >= 0 && SW > 0) {
+      float* sl = stk + tree->save_slot[0] * SW * FK_BLOCK;
+      if (SW == 7) { sl[0] = px; sl[FK_BLOCK] = py; sl[2 * FK_BLOCK] = pz; sl += 3 * FK_BLOCK; }
+      sl[0] = rot.x; sl[FK_BLOCK] = rot.y; sl[2 * FK_BLOCK] = rot.z; sl[3 * FK_BLOCK] = rot.w;
     }
     if (STAGED) {
       float* o = outb + tid * row;
@@ -124,19 +128,27 @@ __global__ __launch_bounds__(FK_BLOCK) void fk_batch_kernel(const FkTree* __rest
     float ppx = cpx, ppy = cpy, ppz = cpz;
     f4 prot = crot;
     if (src >= 0) {   // wave-uniform: this body is not the first child of the body before it
-      const float* par = stk + src * 7 * FK_BLOCK;
-      ppx = par[0]; ppy = par[FK_BLOCK]; ppz = par[2 * FK_BLOCK];
-      prot = f4{par[3 * FK_BLOCK], par[4 * FK_BLOCK], par[5 * FK_BLOCK], par[6 * FK_BLOCK]};
+      if (STAGED) {
+        const int pj = tree->parent[j];
+        const float* po = outb + tid * row + 3 * pj;
+        ppx = po[0]; ppy = po[1]; ppz = po[2];
+        const float* par = stk + src * 4 * FK_BLOCK;
+        prot = f4{par[0], par[FK_BLOCK], par[2 * FK_BLOCK], par[3 * FK_BLOCK]};
+      } else {
+        const float* par = stk + src * 7 * FK_BLOCK;
+        ppx = par[0]; ppy = par[FK_BLOCK]; ppz = par[2 * FK_BLOCK];
+        prot = f4{par[3 * FK_BLOCK], par[4 * FK_BLOCK], par[5 * FK_BLOCK], par[6 * FK_BLOCK]};
+      }
     }
     float wx, wy, wz;
     qrot_xyzw(prot, tx, ty, tz, wx, wy, wz);
     float px = ppx + wx, py = ppy + wy, pz = ppz + wz;
     f4 rot = qmul_xyzw(prot, cr);
     cpx = px; cpy = py; cpz = pz; crot = rot;
-    if (dst >= 0) {
-      float* cur = stk + dst * 7 * FK_BLOCK;
-      cur[0] = px; cur[FK_BLOCK] = py; cur[2 * FK_BLOCK] = pz;
-      cur[3 * FK_BLOCK] = rot.x; cur[4 * FK_BLOCK] = rot.y; cur[5 * FK_BLOCK] = rot.z; cur[6 * FK_BLOCK] = rot.w;
+    if (dst >= 0 && SW > 0) {
+      float* cur = stk + dst * SW * FK_BLOCK;
+      if (SW == 7) { cur[0] = px; cur[FK_BLOCK] = py; cur[2 * FK_BLOCK] = pz; cur += 3 * FK_BLOCK; }
+      cur[0] = rot.x; cur[FK_BLOCK] = rot.y; cur[2 * FK_BLOCK] = rot.z; cur[3 * FK_BLOCK] = rot.w;
     }
     if (STAGED) {
       float* o = outb + tid * row + 3 * j;
@@ -202,14 +214,15 @@ extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree* d_tree, int nbody, 
                                           hipStream_t stream) {
   if (B <= 0) return hipSuccess;
   int blocks = gmr_fk_blocks(nbody, B);
-  size_t smem = (size_t)nslot * 7 * gmr::FK_BLOCK * sizeof(float);
+  size_t smem = (size_t)nslot * 7 * gmr::FK_BLOCK * sizeof(float);   // direct variant: parked (pos, rot)
   // 16-B aligned destinations: LDS-staged, fully coalesced output
   // (the block strides FK_BLOCK * nbody * 12 B and * 16 B are multiples of 16)
   const size_t stage_bytes = (size_t)gmr::FK_BLOCK * nbody * (d_body_rot ? 7 : 3) * sizeof(float);
   const bool staged = (reinterpret_cast<uintptr_t>(d_body_pos) & 15u) == 0 &&
-                      (reinterpret_cast<uintptr_t>(d_body_rot) & 15u) == 0 && smem + stage_bytes <= 160 * 1024 - 1024;
+                      (reinterpret_cast<uintptr_t>(d_body_rot) & 15u) == 0 && stage_bytes <= 160 * 1024 - 8192;
   if (staged) {
-    smem += stage_bytes;
+    // staged variant: parent positions are re-read from the staging area; only rotations are parked
+    smem = (size_t)nslot * 4 * gmr::FK_BLOCK * sizeof(float) + stage_bytes;
     static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in once per process
     if (!attr_set) {
       hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(gmr::fk_batch_kernel<true>),

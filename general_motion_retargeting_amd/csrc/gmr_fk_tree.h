@@ -13,6 +13,7 @@ struct FkTree {
   short depth[FK_MAX_BODIES];
   short load_slot[FK_MAX_BODIES];              // LDS slot holding the parent transform, or -1: parent == previous body
   short save_slot[FK_MAX_BODIES];              // LDS slot this body's transform is parked in (>= 2 children), or -1
+  short parent[FK_MAX_BODIES];                 // parent body (0 for body 0): staged outputs are re-read as parent transforms
   short chain[FK_MAX_BODIES * FK_MAX_DEPTH];   // [nbody][maxd] packed with stride maxd
   float local_t[FK_MAX_BODIES * 3];
   float local_r[FK_MAX_BODIES * 4];            // xyzw, un-normalised (kinematics_model.py:119-123)
