@@ -93,14 +93,14 @@ namespace gmr {
 
 // ---------------------------------------------------------------------------------------------
 // FK: mj_kinematics semantics (App. A.3), evaluated by pointer jumping.  lane b < nb.
-// Result: (pos, quat) per body at sm[L.xa + 7 b], world hinge axes at sm[L.xaxis + 3 b].
+// Result: (pos, quat) per body at sm[L.o.xa + 7 b], world hinge axes at sm[L.o.xaxis + 3 b].
 // ---------------------------------------------------------------------------------------------
-template <int NW>
-__device__ __forceinline__ void fk_wave(const IkLayout& L, double* sm, const short* hop, const short* depth,
+template <int NW, class LT>
+__device__ __forceinline__ void fk_wave(const LT& L, double* sm, const short* hop, const short* depth,
                                         const short* body_hinge, int lane, Prof& pr) {
   PROF_BEGIN(pr);
   const int nb = L.nb;
-  double* q = sm + L.q;
+  double* q = sm + L.o.q;
   d3 pos = {0, 0, 0};
   d4 quat = {1, 0, 0, 0};
   int dep = 0;
@@ -112,13 +112,13 @@ __device__ __forceinline__ void fk_wave(const IkLayout& L, double* sm, const sho
       q[3] = quat.w; q[4] = quat.x; q[5] = quat.y; q[6] = quat.z;
       pos = d3{q[0], q[1], q[2]};
     } else {
-      const double* bq = sm + L.body_quat + 4 * lane;
-      const double* bp = sm + L.body_pos + 3 * lane;
+      const double* bq = sm + L.o.body_quat + 4 * lane;
+      const double* bp = sm + L.o.body_pos + 3 * lane;
       quat = d4{bq[0], bq[1], bq[2], bq[3]};
       pos = d3{bp[0], bp[1], bp[2]};
       int h = body_hinge[lane];
       if (h >= 0) {
-        const double* ax = sm + L.axis + 3 * lane;
+        const double* ax = sm + L.o.axis + 3 * lane;
         double th = q[7 + h];
         if (th != 0.0) quat = qmul(quat, axis_angle(d3{ax[0], ax[1], ax[2]}, th));
       }
@@ -127,14 +127,14 @@ __device__ __forceinline__ void fk_wave(const IkLayout& L, double* sm, const sho
   // after round r a body's transform is relative to its ancestor 2^(r+1) levels up (or the world);
   // rounds alternate between the two buffers so that one barrier per round suffices
   for (int r = 0; r < L.nhop; r++) {
-    double* wb = sm + ((r & 1) ? L.xa : L.xb);
+    double* wb = sm + ((r & 1) ? L.o.xa : L.o.xb);
     if (lane < nb) {
       double* o = wb + 7 * lane;
       o[0] = pos.x; o[1] = pos.y; o[2] = pos.z; o[3] = quat.w; o[4] = quat.x; o[5] = quat.y; o[6] = quat.z;
     }
     WSYNC();
     if (lane < nb && dep >= (1 << r)) {
-      const double* a = wb + 7 * hop[r * nb + lane];
+      const double* a = wb + 7 * hop[r * L.o.cap.nb + lane];
       d4 qa = {a[3], a[4], a[5], a[6]};
       pos = d3{a[0], a[1], a[2]} + qrot(qa, pos);
       quat = qmul(qa, quat);
@@ -144,12 +144,12 @@ __device__ __forceinline__ void fk_wave(const IkLayout& L, double* sm, const sho
   if (L.nhop > 0 && ((L.nhop - 1) & 1)) WSYNC();
   if (lane < nb) {
     quat = qnormalize(quat);
-    double* o = sm + L.xa + 7 * lane;
+    double* o = sm + L.o.xa + 7 * lane;
     o[0] = pos.x; o[1] = pos.y; o[2] = pos.z; o[3] = quat.w; o[4] = quat.x; o[5] = quat.y; o[6] = quat.z;
     if (body_hinge[lane] >= 0) {
-      const double* ax = sm + L.axis + 3 * lane;
+      const double* ax = sm + L.o.axis + 3 * lane;
       d3 aw = qrot(quat, d3{ax[0], ax[1], ax[2]});
-      double* xa = sm + L.xaxis + 3 * lane;
+      double* xa = sm + L.o.xaxis + 3 * lane;
       xa[0] = aw.x; xa[1] = aw.y; xa[2] = aw.z;
     }
   }
@@ -161,22 +161,22 @@ __device__ __forceinline__ void fk_wave(const IkLayout& L, double* sm, const sho
 // residuals of the stage's tasks (mink FrameTask.compute_error) and their unweighted norm
 // (motion_retarget.py:188-200).  lane k < K.  Returns E in every lane.
 // ---------------------------------------------------------------------------------------------
-template <int NW>
-__device__ __forceinline__ double errors_wave(const IkLayout& L, double* sm, const short* task_body,
+template <int NW, class LT>
+__device__ __forceinline__ double errors_wave(const LT& L, double* sm, const short* task_body,
                                               const short* task_human, int K, int lane, Prof& pr) {
   PROF_BEGIN(pr);
   double ss = 0.0;
   if (lane < K) {
     int b = task_body[lane], h = task_human[lane];
-    const double* x = sm + L.xa + 7 * b;
-    const double* tg = sm + L.tgt + 7 * h;
+    const double* x = sm + L.o.xa + 7 * b;
+    const double* tg = sm + L.o.tgt + 7 * h;
     double e[6], aux[3];
     se3_log_rel(d3{x[0], x[1], x[2]}, d4{x[3], x[4], x[5], x[6]}, d3{tg[0], tg[1], tg[2]},
                 d4{tg[3], tg[4], tg[5], tg[6]}, e, aux);
-    double* eo = sm + L.e + 6 * lane;
+    double* eo = sm + L.o.e + 6 * lane;
 #pragma unroll
     for (int r = 0; r < 6; r++) { eo[r] = e[r]; ss += e[r] * e[r]; }
-    double* ao = sm + L.eaux + 3 * lane;     // a, sin|w|, cos|w|: reused by the Jl^-1 phase
+    double* ao = sm + L.o.eaux + 3 * lane;     // a, sin|w|, cos|w|: reused by the Jl^-1 phase
     ao[0] = aux[0]; ao[1] = aux[1]; ao[2] = aux[2];
   }
   ss = wave_sum(ss);
@@ -195,28 +195,28 @@ struct StageTabs {
 };
 
 // (a) lane = task: M_k = -Jl^-1(e_k) (blocks -A, -B), weighted residual; returns the LM term mu
-template <int NW>
-__device__ __forceinline__ double jlog_phase(const IkLayout& L, double* sm, int stage, double lm_damping, int lane,
+template <int NW, class LT>
+__device__ __forceinline__ double jlog_phase(const LT& L, double* sm, int stage, double lm_damping, int lane,
                                              Prof& pr) {
   PROF_BEGIN(pr);
   const int K = L.K[stage];
-  const double* wpos = sm + L.wpos[stage];
-  const double* wrot = sm + L.wrot[stage];
+  const double* wpos = sm + L.o.wpos[stage];
+  const double* wrot = sm + L.o.wrot[stage];
   double mu = 0.0;
   if (lane < K) {
-    const double* e = sm + L.e + 6 * lane;
+    const double* e = sm + L.o.e + 6 * lane;
     double ee[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ee[r] = e[r];
-    const double* ax = sm + L.eaux + 3 * lane;
+    const double* ax = sm + L.o.eaux + 3 * lane;
     const double aux[3] = {ax[0], ax[1], ax[2]};
     m3 A, B;
     se3_jlinv_aux(ee, aux, A, B);
-    double* M = sm + L.M + 18 * lane;
+    double* M = sm + L.o.M + 18 * lane;
 #pragma unroll
     for (int i = 0; i < 9; i++) { M[i] = -A.a[i]; M[9 + i] = -B.a[i]; }
     double wp = wpos[lane], wr = wrot[lane];
-    double* we = sm + L.we + 6 * lane;
+    double* we = sm + L.o.we + 6 * lane;
 #pragma unroll
     for (int r = 0; r < 6; r++) {
       double v = (r < 3 ? wp : wr) * ee[r];
@@ -231,14 +231,15 @@ __device__ __forceinline__ double jlog_phase(const IkLayout& L, double* sm, int 
 }
 
 // (b) virtual lane = (task, dof) pair: weighted task-Jacobian column W_k * (-Jl^-1(e_k)) * J_body[:, d]
-__device__ __forceinline__ void pairs_phase(const IkLayout& L, double* sm, int stage, const StageTabs& tb,
+template <class LT>
+__device__ __forceinline__ void pairs_phase(const LT& L, double* sm, int stage, const StageTabs& tb,
                                             const short* hinge_body, int vlane, int nvl) {
   const int P = L.P[stage];
-  const double* wpos = sm + L.wpos[stage];
-  const double* wrot = sm + L.wrot[stage];
-  double* Jw = sm + L.Jw;
-  double* cpart = sm + L.cpart;
-  const double* X = sm + L.xa;
+  const double* wpos = sm + L.o.wpos[stage];
+  const double* wrot = sm + L.o.wrot[stage];
+  double* Jw = sm + L.o.Jw;
+  double* cpart = sm + L.o.cpart;
+  const double* X = sm + L.o.xa;
   for (int p = vlane; p < P; p += nvl) {
     const unsigned info = (unsigned short)tb.pair_task[p];       // [3:0] task, [9:4] dof, [15:10] task body
     const int k = info & 15u, dof = (info >> 4) & 63u, b = info >> 10;
@@ -255,13 +256,13 @@ __device__ __forceinline__ void pairs_phase(const IkLayout& L, double* sm, int s
       ang = qrot(q0, d3{a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0});
       lin = cross(ang, pb - d3{X[0], X[1], X[2]});
     } else {
-      const double* xa = sm + L.xaxis + 3 * c;
+      const double* xa = sm + L.o.xaxis + 3 * c;
       ang = d3{xa[0], xa[1], xa[2]};
       lin = cross(ang, pb - d3{X[7 * c], X[7 * c + 1], X[7 * c + 2]});
     }
     d3 jl = qrot_inv(qb, lin), ja = qrot_inv(qb, ang);   // body-frame Jacobian column
-    const double* M = sm + L.M + 18 * k;
-    const double* we = sm + L.we + 6 * k;
+    const double* M = sm + L.o.M + 18 * k;
+    const double* we = sm + L.o.we + 6 * k;
     double wp = wpos[k], wr = wrot[k];
     double* o = Jw + 6 * p;
     double cp = 0.0;
@@ -282,26 +283,27 @@ __device__ __forceinline__ void pairs_phase(const IkLayout& L, double* sm, int s
 }
 
 // (c) lane = dof: gather c; bounds of the limited hinges (mink ConfigurationLimit)
-__device__ __forceinline__ void cvec_phase(const IkLayout& L, double* sm, int stage, const StageTabs& tb,
+template <class LT>
+__device__ __forceinline__ void cvec_phase(const LT& L, double* sm, int stage, const StageTabs& tb,
                                            const short* limited, double limit_gain, int lane) {
   const int K = L.K[stage], nv = L.nv;
-  const double* cpart = sm + L.cpart;
+  const double* cpart = sm + L.o.cpart;
   if (lane < nv) {
     int idx[GMR_MAX_TASKS];
 #pragma unroll
-    for (int k = 0; k < GMR_MAX_TASKS; k++) idx[k] = k < K ? (int)tb.pair_index[k * nv + lane] : -1;
+    for (int k = 0; k < GMR_MAX_TASKS; k++) idx[k] = k < K ? (int)tb.pair_index[k * L.o.nvp + lane] : -1;
     double cc = 0.0;
 #pragma unroll
     for (int k = 0; k < GMR_MAX_TASKS; k++) cc += idx[k] >= 0 ? cpart[idx[k]] : 0.0;
-    (sm + L.c)[lane] = cc;
+    (sm + L.o.c)[lane] = cc;
     double lo = -INFINITY, hi = INFINITY;
     if (lane >= 6 && limited[lane - 6]) {
-      double th = (sm + L.q)[7 + lane - 6];
-      hi = limit_gain * ((sm + L.range_hi)[lane - 6] - th);
-      lo = -limit_gain * (th - (sm + L.range_lo)[lane - 6]);
+      double th = (sm + L.o.q)[7 + lane - 6];
+      hi = limit_gain * ((sm + L.o.range_hi)[lane - 6] - th);
+      lo = -limit_gain * (th - (sm + L.o.range_lo)[lane - 6]);
     }
-    (sm + L.lo)[lane] = lo;
-    (sm + L.hi)[lane] = hi;
+    (sm + L.o.lo)[lane] = lo;
+    (sm + L.o.hi)[lane] = hi;
   }
 }
 
@@ -316,12 +318,13 @@ __device__ __forceinline__ double dot6v(const double* a, const double* b) {
   return (a0.x * b0.x + a0.y * b0.y + a1.x * b1.x) + (a1.y * b1.y + a2.x * b2.x + a2.y * b2.y);
 }
 
-__device__ __forceinline__ void hacc_phase(const IkLayout& L, double* sm, int stage, const StageTabs& tb, double diag,
+template <class LT>
+__device__ __forceinline__ void hacc_phase(const LT& L, double* sm, int stage, const StageTabs& tb, double diag,
                                            int vlane) {
-  const int ldh = L.ldh, nl = L.nlanes, ntrip = L.ntrip[stage];
+  const int ldh = L.o.ldh, nl = L.nlanes, ntrip = L.ntrip[stage];
   const bool paired = vlane < L.pair_lanes;       // the whole first helper wavefront, or nobody
-  double* __restrict__ H = sm + L.H;
-  const double* __restrict__ J = sm + L.Jw;
+  double* __restrict__ H = sm + L.o.H;
+  const double* __restrict__ J = sm + L.o.Jw;
   const uint32_t* items = tb.items + vlane;
   double acc = 0.0;
   uint32_t n0 = items[0], n1 = items[nl];
@@ -375,11 +378,12 @@ __device__ __forceinline__ void hacc_phase(const IkLayout& L, double* sm, int st
 
 // (d') one wavefront per stream: the schedule is read from the global image (the same words for every
 // stream on the CU: vector-L1 hits) instead of LDS, four slots per trip with the next trip in flight.
-__device__ __forceinline__ void hacc_phase_g(const IkLayout& L, double* sm, int stage,
+template <class LT>
+__device__ __forceinline__ void hacc_phase_g(const LT& L, double* sm, int stage,
                                              const uint32_t* __restrict__ gitems, double diag, int lane) {
-  const int ldh = L.ldh, ntrip = L.ntrip[stage];          // a multiple of 4, 64 lanes
-  double* __restrict__ H = sm + L.H;
-  const double* __restrict__ J = sm + L.Jw;
+  const int ldh = L.o.ldh, ntrip = L.ntrip[stage];          // a multiple of 4, 64 lanes
+  double* __restrict__ H = sm + L.o.H;
+  const double* __restrict__ J = sm + L.o.Jw;
   const uint32_t* p = gitems + lane;
   uint32_t n[4];
 #pragma unroll
@@ -416,8 +420,8 @@ __device__ __forceinline__ void hacc_phase_g(const IkLayout& L, double* sm, int 
 // the whole assembly as seen from the MAIN wave.  NW == 1: all four phases by this wave.  NW > 1:
 // the Jacobian columns are shared by all NW waves, then the helpers assemble H (64*(NW-1) virtual
 // lanes) while this wave gathers c and the bounds; three workgroup barriers per assembly.
-template <int NW>
-__device__ __forceinline__ void build_qp_main(const IkLayout& L, double* sm, int stage, const StageTabs& tb,
+template <int NW, class LT>
+__device__ __forceinline__ void build_qp_main(const LT& L, double* sm, int stage, const StageTabs& tb,
                                               const short* hinge_body, const short* limited, int* ctl,
                                               double damping, double lm_damping, double limit_gain, int lane,
                                               Prof& pr) {
@@ -437,7 +441,7 @@ __device__ __forceinline__ void build_qp_main(const IkLayout& L, double* sm, int
     PROF_END(pr, PH_HACC);
   } else {
     PROF_BEGIN(pr);
-    if (lane == 0) { ctl[0] = CMD_BUILD; ctl[1] = stage; (sm + L.scal)[0] = diag; }
+    if (lane == 0) { ctl[0] = CMD_BUILD; ctl[1] = stage; (sm + L.o.scal)[0] = diag; }
     __syncthreads();                      // B1: helpers see the command, M / we / FK state are final
     pairs_phase(L, sm, stage, tb, hinge_body, lane, 64 * NW);
     __syncthreads();                      // B2: all Jacobian columns written
@@ -452,8 +456,8 @@ __device__ __forceinline__ void build_qp_main(const IkLayout& L, double* sm, int
 }
 
 // helper waves (NW > 1): serve assembly requests until the main wave says EXIT
-template <int NW>
-__device__ __forceinline__ void helper_loop(const IkLayout& L, double* sm, const uint32_t* sw, const short* si,
+template <int NW, class LT>
+__device__ __forceinline__ void helper_loop(const LT& L, double* sm, const uint32_t* sw, const short* si,
                                             const short* hinge_body, const int* ctl, int wave, int lane,
                                             Prof& hp) {
   TreeState bs = {0ull, 0ull};            // bound sets of the QP (identical in every wavefront)
@@ -464,9 +468,9 @@ __device__ __forceinline__ void helper_loop(const IkLayout& L, double* sm, const
     const int cmd = ctl[0];
     if (cmd == CMD_EXIT) return;
     const int stage = ctl[1];
-    const double diag = (sm + L.scal)[0];
-    StageTabs tb = {si + L.i_task_body[stage], si + L.i_task_human[stage], si + L.i_pair_task[stage],
-                    si + L.i_pair_dof[stage], si + L.i_pair_index[stage], sw + L.w_items[stage]};
+    const double diag = (sm + L.o.scal)[0];
+    StageTabs tb = {si + L.o.i_task_body[stage], si + L.o.i_task_human[stage], si + L.o.i_pair_task[stage],
+                    si + L.o.i_pair_dof[stage], si + L.o.i_pair_index[stage], sw + L.w_items[stage]};
     PROF_BEGIN(hp);
     pairs_phase(L, sm, stage, tb, hinge_body, wave * 64 + lane, 64 * NW);
     PROF_END(hp, PH_PAIRS);
@@ -488,18 +492,18 @@ __device__ __forceinline__ void helper_loop(const IkLayout& L, double* sm, const
 // unique minimiser as DAQP behind qpsolvers.  Block principal pivoting over the bound sets; each
 // round is one dense Cholesky of H with the rows/columns of the fixed variables replaced by the
 // identity.  `st` (0 free, -1 at lower, +1 at upper) is carried from solve to solve (warm start).
-// Returns 0 ok / <0 failure; the solution is left in sm[L.x].
+// Returns 0 ok / <0 failure; the solution is left in sm[L.o.x].
 // ---------------------------------------------------------------------------------------------
-template <int NVP, int NW>
-__device__ __forceinline__ int solve_qp_regs(const IkLayout& L, double* sm, int lane, int& st, Prof& pr) {
+template <int NVP, int NW, class LT>
+__device__ __forceinline__ int solve_qp_regs(const LT& L, double* sm, int lane, int& st, Prof& pr) {
   constexpr int LDK = NVP + 1;
-  const int n = L.nv, ldh = L.ldh;
-  const double* H = sm + L.H;
-  double* Kt = sm + L.Kt;
+  const int n = L.nv, ldh = L.o.ldh;
+  const double* H = sm + L.o.H;
+  double* Kt = sm + L.o.Kt;
   const bool act = lane < n;
   const bool row = lane < NVP;
-  const double lo = act ? (sm + L.lo)[lane] : 0.0, hi = act ? (sm + L.hi)[lane] : 0.0;
-  const double ci = act ? (sm + L.c)[lane] : 0.0;
+  const double lo = act ? (sm + L.o.lo)[lane] : 0.0, hi = act ? (sm + L.o.hi)[lane] : 0.0;
+  const double ci = act ? (sm + L.o.c)[lane] : 0.0;
   const double* Hrow = H + (act ? lane : 0) * ldh;
   if (!act || (st < 0 && !(lo > -INFINITY)) || (st > 0 && !(hi < INFINITY))) st = 0;
   const double dual_tol = 1e-13 * (1.0 + wave_max(fabs(ci)));
@@ -614,7 +618,7 @@ __device__ __forceinline__ int solve_qp_regs(const IkLayout& L, double* sm, int 
     const unsigned long long vm = __ballot(viol);
     PROF_END(pr, PH_MULT);
     if (vm == 0ull) {
-      if (act) (sm + L.x)[lane] = fmin(fmax(x, lo), hi);
+      if (act) (sm + L.o.x)[lane] = fmin(fmax(x, lo), hi);
       WSYNC();
       return GMR_STATUS_OK;
     }
@@ -632,11 +636,11 @@ __device__ __forceinline__ int solve_qp_regs(const IkLayout& L, double* sm, int 
 // ---------------------------------------------------------------------------------------------
 // mj_integratePos with v = dq/dt (App. A.7): lane 0 the free joint, lane 6+h hinge h
 // ---------------------------------------------------------------------------------------------
-template <int NW>
-__device__ __forceinline__ void integrate_wave(const IkLayout& L, double* sm, double dt, int lane, Prof& pr) {
+template <int NW, class LT>
+__device__ __forceinline__ void integrate_wave(const LT& L, double* sm, double dt, int lane, Prof& pr) {
   PROF_BEGIN(pr);
-  double* q = sm + L.q;
-  const double* dq = sm + L.x;
+  double* q = sm + L.o.q;
+  const double* dq = sm + L.o.x;
   if (lane == 0) {
     // v = dq / dt followed by dt * v (solve_ik / mj_integratePos) is dq to 1 ulp: integrate dq directly
     q[0] += dq[0]; q[1] += dq[1]; q[2] += dq[2];
@@ -658,12 +662,12 @@ __device__ __forceinline__ void integrate_wave(const IkLayout& L, double* sm, do
 // ---------------------------------------------------------------------------------------------
 // target preprocessing (motion_retarget.py:203-270).  lane b < nhuman.
 // ---------------------------------------------------------------------------------------------
-template <int NW>
-__device__ __forceinline__ void preprocess_wave(const IkLayout& L, double* sm, const short* is_foot, int human_root,
+template <int NW, class LT>
+__device__ __forceinline__ void preprocess_wave(const LT& L, double* sm, const short* is_foot, int human_root,
                                                 double ground_offset, int flags, int lane, Prof& pr) {
   PROF_BEGIN(pr);
-  const double* raw = sm + L.raw;
-  double* tgt = sm + L.tgt;
+  const double* raw = sm + L.o.raw;
+  double* tgt = sm + L.o.tgt;
   double z = INFINITY;
   d3 p = {0, 0, 0};
   d4 uq = {1, 0, 0, 0};
@@ -671,7 +675,7 @@ __device__ __forceinline__ void preprocess_wave(const IkLayout& L, double* sm, c
   if (on) {
     const double* in = raw + 7 * lane;
     const double* rp = raw + 7 * human_root;
-    const double* sc = sm + L.scale;
+    const double* sc = sm + L.o.scale;
     double sr = sc[human_root];
     d3 srp = {sr * rp[0], sr * rp[1], sr * rp[2]};
     if (lane == human_root) p = srp;
@@ -679,8 +683,8 @@ __device__ __forceinline__ void preprocess_wave(const IkLayout& L, double* sm, c
       double s = sc[lane];
       p = d3{(in[0] - rp[0]) * s + srp.x, (in[1] - rp[1]) * s + srp.y, (in[2] - rp[2]) * s + srp.z};
     }
-    const double* qo = sm + L.quat_off + 4 * lane;
-    const double* po = sm + L.pos_off + 3 * lane;
+    const double* qo = sm + L.o.quat_off + 4 * lane;
+    const double* po = sm + L.o.pos_off + 3 * lane;
     d4 q = qnormalize(d4{in[3], in[4], in[5], in[6]});
     uq = qnormalize(qmul(q, qnormalize(d4{qo[0], qo[1], qo[2], qo[3]})));
     p = p + qrot(uq, d3{po[0], po[1], po[2]});
@@ -702,7 +706,7 @@ __device__ __forceinline__ void preprocess_wave(const IkLayout& L, double* sm, c
 // the kernel
 // ---------------------------------------------------------------------------------------------
 template <int NVP, int NW>
-__global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __restrict__ image, IkLayout L, IkParams P,
+__global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __restrict__ image, IkLay<NVP, NW> L, IkParams P,
                                                              int S, int T, const double* __restrict__ q0,
                                                              const double* __restrict__ human,
                                                              const int32_t* __restrict__ len, int flags,
@@ -721,15 +725,15 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
   for (int i = 0; i < PH_COUNT; i++) pr.acc[i] = 0;
   const unsigned long long k_t0 = __builtin_amdgcn_s_memtime(), k_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  uint32_t* sw = reinterpret_cast<uint32_t*>(smem + L.n_double);
-  short* si = reinterpret_cast<short*>(sw + L.n_word);
-  int* ctl = reinterpret_cast<int*>(sw + L.w_ctl);
-  short* hop = si + L.i_hop;
-  short* depth = si + L.i_depth;
-  short* body_hinge = si + L.i_body_hinge;
-  short* hinge_body = si + L.i_hinge_body;
-  short* limited = si + L.i_limited;
-  short* is_foot = si + L.i_is_foot;
+  short* si = reinterpret_cast<short*>(smem + L.o.n_double);
+  uint32_t* sw = reinterpret_cast<uint32_t*>(si + L.o.n_short);
+  int* ctl = reinterpret_cast<int*>(sw + L.o.w_ctl);
+  short* hop = si + L.o.i_hop;
+  short* depth = si + L.o.i_depth;
+  short* body_hinge = si + L.o.i_body_hinge;
+  short* hinge_body = si + L.o.i_hinge_body;
+  short* limited = si + L.o.i_limited;
+  short* is_foot = si + L.o.i_is_foot;
 
   // ---- stage the constants: one coalesced copy of the host-built LDS image ---------------------
   const int nv = L.nv, nq = L.nq, nhum = L.nhum;
@@ -752,7 +756,7 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
   const int max_iter = P.max_iter, human_root = P.human_root;
   const int use0 = P.use0, use1 = P.use1;
 
-  for (int i = lane; i < nq; i += 64) (sm + L.q)[i] = q0[(size_t)s * nq + i];
+  for (int i = lane; i < nq; i += 64) (sm + L.o.q)[i] = q0[(size_t)s * nq + i];
   WSYNC();
   fk_wave<NW>(L, sm, hop, depth, body_hinge, lane, pr);
 
@@ -770,8 +774,8 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
     if (lane + 64 < (int)fstride) r1 = hs[lane + 64];
   }
   for (int t = 0; t < Ts; t++) {
-    if (lane < (int)fstride) (sm + L.raw)[lane] = r0;
-    if (lane + 64 < (int)fstride) (sm + L.raw)[lane + 64] = r1;
+    if (lane < (int)fstride) (sm + L.o.raw)[lane] = r0;
+    if (lane + 64 < (int)fstride) (sm + L.o.raw)[lane + 64] = r1;
     // prefetch the next frame (nhuman*7 <= 128 doubles)
     if (t + 1 < Ts) {
       const double* nx = hs + (size_t)(t + 1) * fstride;
@@ -784,13 +788,13 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
       preprocess_wave<NW>(L, sm, is_foot, human_root, ground_offset, flags, lane, pr);
       for (int stage = 0; stage < 2; stage++) {
         if (!(stage == 0 ? use0 : use1)) continue;
-        const StageTabs tb = {si + L.i_task_body[stage], si + L.i_task_human[stage], si + L.i_pair_task[stage],
-                              si + L.i_pair_dof[stage], si + L.i_pair_index[stage],
+        const StageTabs tb = {si + L.o.i_task_body[stage], si + L.o.i_task_human[stage], si + L.o.i_pair_task[stage],
+                              si + L.o.i_pair_dof[stage], si + L.o.i_pair_index[stage],
                               NW == 1 ? reinterpret_cast<const uint32_t*>(image) + L.g_items[stage] : sw + L.w_items[stage]};
         const int K = L.K[stage];
         if (h_stage != stage) {
           // structural zeros of H are never written by the schedule: clear when the pattern changes
-          for (int i = lane; i < nv * L.ldh; i += 64) (sm + L.H)[i] = 0.0;
+          for (int i = lane; i < nv * L.o.ldh; i += 64) (sm + L.o.H)[i] = 0.0;
           h_stage = stage;
           WSYNC();
         }
@@ -820,7 +824,7 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
       }
     }
     const size_t f = (size_t)s * T + t;
-    for (int i = lane; i < nq; i += 64) q_out[f * nq + i] = (sm + L.q)[i];
+    for (int i = lane; i < nq; i += 64) q_out[f * nq + i] = (sm + L.o.q)[i];
     if (lane == 0) { nsolve[2 * f] = ns0; nsolve[2 * f + 1] = ns1; }
     WSYNC();
   }
@@ -849,8 +853,8 @@ static hipError_t launch_nvp(const uint4* d_image, const gmr::IkLayout* L, const
                              const double* d_q0, const double* d_human,
                              const int32_t* d_len, int flags, double* d_q_out, int32_t* d_nsolve, int32_t* d_status,
                              hipStream_t stream, unsigned long long* d_prof) {
-  hipLaunchKernelGGL((gmr::ik_streams_kernel<NVP, NW>), dim3(S), dim3(64 * NW), L->smem_bytes, stream, d_image, *L,
-                     *P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, d_prof);
+  hipLaunchKernelGGL((gmr::ik_streams_kernel<NVP, NW>), dim3(S), dim3(64 * NW), L->smem_bytes, stream, d_image,
+                     gmr::IkLay<NVP, NW>(static_cast<const gmr::IkDims&>(*L)), *P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, d_prof);
   return hipGetLastError();
 }
 

@@ -13,27 +13,117 @@ namespace gmr {
 
 constexpr int IK_MAX_HOPS = 5;  // pointer-jumping rounds of the FK: 2^5 = 32 > GMR_MAX_DEPTH
 
-struct IkLayout {
-  // dimensions
-  int nb, nh, nq, nv, nvp, nw, nhum, maxd, nhop, ldh;
-  int tree_ok, tree_nt;          // limb/trunk decomposition usable by the 4-wavefront tree solver
-  int K[2], P[2], nitem[2], ntrip[2], nlanes, pair_lanes;
+// rows of the dense register-resident factorisation are padded to one of these sizes = the SIZE CLASS of a
+// robot.  Every LDS offset is a compile-time constant of the class (and of the launch shape), so that the
+// kernel holds no layout in scalar registers and folds the offsets into the LDS instructions: with the ~95
+// runtime offsets of a per-robot layout the wave-uniform state did not fit the 102 SGPRs and one instruction
+// in six was an SGPR spill or reload (v_writelane / v_readlane through ten VGPRs, plus their s_nop hazards).
+struct IkCaps { int nb, nh, k, p, nhum; };     // capacity: bodies, hinges, tasks / stage, (task, dof) pairs / stage, human bodies
+constexpr IkCaps ik_caps(int nvp) {
+  return nvp == 28 ? IkCaps{34, 22, 16, 160, 16}
+       : nvp == 32 ? IkCaps{34, 26, 16, 160, 16}
+       : nvp == 36 ? IkCaps{40, 30, 16, 160, 16}
+                   : IkCaps{GMR_MAX_BODIES, GMR_MAX_HINGES, GMR_MAX_TASKS, GMR_MAX_PAIRS, GMR_MAX_HUMAN};
+}
+
+struct IkOffsets {
+  IkCaps cap;
+  int nvp;                       // the class: padded row count of the dense solver, row stride of pair_index
+  int ldh;                       // row stride of H (odd: conflict-free column reads)
   // offsets in doubles
   int body_pos, body_quat, axis, range_lo, range_hi, scale, pos_off, quat_off;
   int wpos[2], wrot[2];
   int q, xa, xb, xaxis, raw, tgt, e, eaux, we, M, Jw, cpart, H, Kt, c, x, lo, hi, scal, tr_spart, tr_rpart;
   int n_double;
-  // offsets in 32-bit words (after the doubles): the H-assembly schedule
-  int w_items[2], w_istart[2], w_ctl, w_tr_mask, w_tr_cnt;
-  int n_word;
-  // nw == 1: the schedule stays in the global image (read through the vector L1, identical for all streams)
-  // at these 32-bit word offsets from the image start; -1 when it lives in LDS (w_items)
-  int g_items[2], image_bytes;
-  // offsets in shorts (after the words)
+  // offsets in shorts (after the doubles)
   int i_hop, i_depth, i_body_hinge, i_hinge_body, i_limited, i_is_foot, i_tree_limb, i_tree_trunk;
   int i_task_body[2], i_task_human[2], i_pair_task[2], i_pair_dof[2], i_pair_index[2];
-  int n_short;
+  int n_short;                   // padded to a multiple of 8 (the words start 16-byte aligned)
+  // offsets in 32-bit words (after the shorts); the H-assembly schedule (runtime size) comes last
+  int w_ctl, w_tr_mask, w_tr_cnt, w_items0;
+  int fixed_bytes;               // bytes up to the schedule
+};
+
+constexpr int ik_max(int a, int b) { return a > b ? a : b; }
+
+constexpr IkOffsets ik_offsets(int nvp, int nw) {
+  IkOffsets L{};
+  const IkCaps cp = ik_caps(nvp);
+  L.cap = cp;
+  L.nvp = nvp;
+  L.ldh = nvp + 1;               // 29 / 33 / 37 / 49: odd
+  int o = 0;
+  L.body_pos = o; o += 3 * cp.nb; L.body_quat = o; o += 4 * cp.nb; L.axis = o; o += 3 * cp.nb;
+  L.range_lo = o; o += cp.nh; L.range_hi = o; o += cp.nh;
+  L.scale = o; o += cp.nhum; L.pos_off = o; o += 3 * cp.nhum; L.quat_off = o; o += 4 * cp.nhum;
+  for (int s = 0; s < 2; s++) { L.wpos[s] = o; o += cp.k; L.wrot[s] = o; o += cp.k; }
+  L.q = o; o += 7 + cp.nh + 1;
+  L.xa = o; o += 7 * cp.nb + 1;                    // FK result; the second buffer of the FK rounds aliases Jw
+  L.xaxis = o; o += 3 * cp.nb;
+  L.tgt = o; o += 7 * cp.nhum + 1;
+  L.e = o; o += 6 * cp.k; L.eaux = o; o += 3 * cp.k; L.we = o; o += 6 * cp.k;
+  L.M = o; o += ik_max(18 * cp.k, 7 * cp.nhum + 1);
+  L.raw = L.M;                                     // the raw frame is consumed by the preprocess step, before any solve
+  if (o & 1) o++;                                  // Jw rows (48 B) are read as three 16-B pieces
+  L.Jw = o; o += ik_max(6 * cp.p, 7 * cp.nb + 1);
+  L.cpart = o; o += cp.p;
+  L.xb = L.Jw;                                     // FK runs between solves, when the assembly scratch is dead
+  // The transpose scratch of the QP solvers (dense: nvp x (nvp+1); tree: 4 x 18 x 19) is only live inside a
+  // solve, when the assembly scratch [e, eaux, we, M, Jw, cpart] is dead: alias it there.
+  {
+    const int need = ik_max(nvp * (nvp + 1), nw == 4 ? 4 * 18 * 19 : 0);
+    const int have = o - L.e;
+    if (have < need) o += need - have;
+    L.Kt = L.e;
+  }
+  if (o & 1) o++;
+  L.H = o; o += nvp * L.ldh + 2;
+  L.c = o; o += nvp; L.x = o; o += nvp; L.lo = o; o += nvp; L.hi = o; o += nvp; L.scal = o; o += 2;
+  L.tr_spart = o; o += nw == 4 ? 4 * 10 * 10 : 0;
+  L.tr_rpart = o; o += nw == 4 ? 4 * 10 : 0;
+  if (o & 1) o++;                                  // every region starts 16-byte aligned
+  L.n_double = o;
+  int i = 0;
+  L.i_hop = i; i += IK_MAX_HOPS * cp.nb; L.i_depth = i; i += cp.nb; L.i_body_hinge = i; i += cp.nb;
+  L.i_hinge_body = i; i += cp.nh; L.i_limited = i; i += cp.nh; L.i_is_foot = i; i += cp.nhum;
+  L.i_tree_limb = i; i += 4 * 8; L.i_tree_trunk = i; i += 10;
+  for (int s = 0; s < 2; s++) {
+    L.i_task_body[s] = i; i += cp.k; L.i_task_human[s] = i; i += cp.k;
+    L.i_pair_task[s] = i; i += cp.p; L.i_pair_dof[s] = i; i += cp.p;
+    L.i_pair_index[s] = i; i += cp.k * nvp;        // [task][dof], row stride nvp
+  }
+  L.n_short = (i + 7) / 8 * 8;
+  int w = 0;
+  L.w_ctl = w; w += 2;
+  L.w_tr_mask = w; w += 16;
+  L.w_tr_cnt = w; w += 4;
+  if (w % 4) w += 4 - w % 4;                       // the schedule starts 16-byte aligned
+  L.w_items0 = w;
+  L.fixed_bytes = L.n_double * 8 + L.n_short * 2 + w * 4;
+  return L;
+}
+
+// what varies per robot inside a class: passed by value to the kernel (the only layout state in SGPRs)
+struct IkDims {
+  int nb, nh, nq, nv, nhum, nhop, tree_ok;
+  int K[2], P[2], ntrip[2], nlanes, pair_lanes;
+  int w_items[2];                // NW > 1: word offset of a stage's schedule from the start of the words
+  int g_items[2];                // NW == 1: the schedule stays in the global image at these word offsets; else -1
   int smem_bytes;
+};
+
+// host-side description of one (robot, task set, launch shape)
+struct IkLayout : IkDims {
+  int nvp, nw, maxd, tree_nt, nitem[2], image_bytes;
+  IkOffsets o;
+};
+
+// device-side: the runtime dims + the class's compile-time offsets (L.o.xxx folds to a constant)
+template <int NVP, int NW>
+struct IkLay : IkDims {
+  static constexpr IkOffsets o = ik_offsets(NVP, NW);
+  IkLay() = default;
+  explicit IkLay(const IkDims& d) : IkDims(d) {}
 };
 
 // rows of the dense register-resident factorisation are padded to one of these sizes
@@ -42,6 +132,17 @@ inline int ik_padded_nv(int nv) {
   if (nv <= 32) return 32;
   if (nv <= 36) return 36;
   if (nv <= 48) return 48;   // generic upper size (GMR_MAX_DOF = 46); none of the shipped robots needs it
+  return -1;
+}
+
+// size class of a (robot, task set): the smallest whose capacities hold it (48 = generic, GMR_MAX_* capacities)
+inline int ik_size_class(const gmr_model_t& m, const gmr_taskset_t& ts) {
+  for (int nvp : {28, 32, 36, 48}) {
+    const IkCaps c = ik_caps(nvp);
+    if (m.nv <= nvp && m.nbody <= c.nb && m.nhinge <= c.nh && ts.nhuman <= c.nhum && ts.ntask[0] <= c.k &&
+        ts.ntask[1] <= c.k && ts.npair[0] <= c.p && ts.npair[1] <= c.p)
+      return nvp;
+  }
   return -1;
 }
 
@@ -227,69 +328,25 @@ inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, co
   L.tree_ok = (nw == 4 && tree.ok) ? 1 : 0;
   L.tree_nt = tree.nt;
   L.nb = m.nbody; L.nh = m.nhinge; L.nq = m.nq; L.nv = m.nv; L.nhum = ts.nhuman;
-  L.nvp = ik_padded_nv(m.nv);
+  L.nvp = ik_size_class(m, ts);
   int maxd = 1;
   for (int b = 0; b < m.nbody; b++) if (m.depth[b] + 1 > maxd) maxd = m.depth[b] + 1;
   L.maxd = maxd;
   L.nhop = 0;
   while ((1 << L.nhop) < maxd) L.nhop++;
-  L.ldh = (m.nv % 2 == 0) ? m.nv + 1 : m.nv + 2;  // odd row stride (in doubles): conflict-free column reads
   for (int s = 0; s < 2; s++) { L.K[s] = ts.ntask[s]; L.P[s] = ts.npair[s]; L.nitem[s] = (int)sch.padded[s].size(); L.ntrip[s] = sch.ntrip[s]; }
   L.nlanes = sch.nlanes;
   L.pair_lanes = sch.pair_lanes;
-  int Kmax = std::max(L.K[0], L.K[1]);
-  int Pmax = std::max(L.P[0], L.P[1]);
-  int o = 0;
-  auto D = [&](int n) { int r = o; o += n; return r; };
-  L.body_pos = D(3 * L.nb); L.body_quat = D(4 * L.nb); L.axis = D(3 * L.nb);
-  L.range_lo = D(L.nh); L.range_hi = D(L.nh);
-  L.scale = D(L.nhum); L.pos_off = D(3 * L.nhum); L.quat_off = D(4 * L.nhum);
-  for (int s = 0; s < 2; s++) { L.wpos[s] = D(L.K[s]); L.wrot[s] = D(L.K[s]); }
-  L.q = D(L.nq + 1);
-  L.xa = D(7 * L.nb + 1);                            // FK result; the second buffer of the FK rounds aliases Jw
-  L.xaxis = D(3 * L.nb);
-  L.tgt = D(7 * L.nhum + 1);
-  L.e = D(6 * Kmax); L.eaux = D(3 * Kmax); L.we = D(6 * Kmax);
-  L.M = D(std::max(18 * Kmax, 7 * L.nhum + 1));
-  L.raw = L.M;                                // the raw frame is consumed by the preprocess step, before any solve
-  if (o & 1) o++;                             // Jw rows (48 B) are read as three 16-B pieces
-  L.Jw = D(std::max(6 * Pmax, 7 * L.nb + 1)); L.cpart = D(Pmax);
-  L.xb = L.Jw;                                // FK runs between solves, when the assembly scratch is dead
-  // The transpose scratch of the QP solvers (dense: nvp x (nvp+1); tree: 4 x 18 x 19) is only live inside a
-  // solve, when the assembly scratch [e, eaux, we, M, Jw, cpart] is dead: alias it there (saves ~11 KB of
-  // LDS per stream = one more resident workgroup per CU in the throughput shape).
-  {
-    const int need = std::max(L.nvp * (L.nvp + 1), nw == 4 ? 4 * 18 * 19 : 0);
-    const int have = o - L.e;
-    if (have < need) D(need - have);
-    L.Kt = L.e;
-  }
-  if (o & 1) o++;
-  L.H = D(L.nv * L.ldh + 2);
-  L.c = D(L.nv); L.x = D(L.nv); L.lo = D(L.nv); L.hi = D(L.nv); L.scal = D(2);
-  L.tr_spart = D(nw == 4 ? 4 * 10 * 10 : 0); L.tr_rpart = D(nw == 4 ? 4 * 10 : 0);
-  L.n_double = o;
-  int w = 0;
-  auto W = [&](int n) { int r = w; w += n; return r; };
-  for (int s = 0; s < 2; s++) { L.w_items[s] = nw == 1 ? 0 : W(L.nitem[s]); L.w_istart[s] = 0; L.g_items[s] = -1; }
-  L.w_ctl = W(2);
-  if (w % 2) w++;
-  L.w_tr_mask = W(16); L.w_tr_cnt = W(4);
-  if (w % 2) w++;
-  L.n_word = w;
-  int i = 0;
-  auto I = [&](int n) { int r = i; i += n; return r; };
-  L.i_hop = I(IK_MAX_HOPS * L.nb); L.i_depth = I(L.nb); L.i_body_hinge = I(L.nb);
-  L.i_hinge_body = I(L.nh); L.i_limited = I(L.nh); L.i_is_foot = I(L.nhum);
-  L.i_tree_limb = I(4 * 8); L.i_tree_trunk = I(10);
+  L.o = ik_offsets(L.nvp > 0 ? L.nvp : 48, nw);
+  // the schedule: in LDS after the fixed part (NW > 1), or only in the global image (NW == 1)
+  int w = L.o.w_items0;
   for (int s = 0; s < 2; s++) {
-    L.i_task_body[s] = I(L.K[s]); L.i_task_human[s] = I(L.K[s]);
-    L.i_pair_task[s] = I(L.P[s]); L.i_pair_dof[s] = I(L.P[s]);
-    L.i_pair_index[s] = I(GMR_MAX_TASKS * L.nv);
+    L.w_items[s] = nw == 1 ? 0 : w;
+    if (nw != 1) w += (L.nitem[s] + 3) / 4 * 4;
+    L.g_items[s] = -1;
   }
-  L.n_short = i;
-  L.smem_bytes = (L.n_double * 8 + L.n_word * 4 + L.n_short * 2 + 15) / 16 * 16;
-  L.image_bytes = (L.smem_bytes + 15) / 16 * 16;
+  L.smem_bytes = L.o.n_double * 8 + L.o.n_short * 2 + w * 4;
+  L.image_bytes = L.smem_bytes;                    // a multiple of 16
   if (nw == 1)
     for (int s = 0; s < 2; s++) { L.g_items[s] = L.image_bytes / 4; L.image_bytes += (L.nitem[s] * 4 + 15) / 16 * 16; }
   return L;
@@ -316,55 +373,55 @@ inline std::vector<char> make_ik_image(const gmr_model_t& m, const gmr_taskset_t
                                        const IkLayout& L) {
   std::vector<char> img((size_t)L.image_bytes, 0);
   double* sm = reinterpret_cast<double*>(img.data());
-  uint32_t* sw = reinterpret_cast<uint32_t*>(sm + L.n_double);
-  short* si = reinterpret_cast<short*>(sw + L.n_word);
+  short* si = reinterpret_cast<short*>(sm + L.o.n_double);
+  uint32_t* sw = reinterpret_cast<uint32_t*>(si + L.o.n_short);
   const int nb = L.nb, nv = L.nv;
   for (int i = 0; i < nb; i++) {
-    for (int a = 0; a < 3; a++) sm[L.body_pos + 3 * i + a] = m.body_pos[i][a];
-    for (int a = 0; a < 4; a++) sm[L.body_quat + 4 * i + a] = m.body_quat[i][a];
+    for (int a = 0; a < 3; a++) sm[L.o.body_pos + 3 * i + a] = m.body_pos[i][a];
+    for (int a = 0; a < 4; a++) sm[L.o.body_quat + 4 * i + a] = m.body_quat[i][a];
     int hh = m.body_hinge[i];
-    for (int a = 0; a < 3; a++) sm[L.axis + 3 * i + a] = hh >= 0 ? m.hinge_axis[hh][a] : 0.0;
+    for (int a = 0; a < 3; a++) sm[L.o.axis + 3 * i + a] = hh >= 0 ? m.hinge_axis[hh][a] : 0.0;
     int dep = m.depth[i];
-    si[L.i_depth + i] = (short)dep;
-    si[L.i_body_hinge + i] = (short)hh;
+    si[L.o.i_depth + i] = (short)dep;
+    si[L.o.i_body_hinge + i] = (short)hh;
     for (int r = 0; r < L.nhop; r++)
-      si[L.i_hop + r * nb + i] = (short)(dep >= (1 << r) ? m.chain[i][dep - (1 << r)] : 0);
+      si[L.o.i_hop + r * L.o.cap.nb + i] = (short)(dep >= (1 << r) ? m.chain[i][dep - (1 << r)] : 0);
   }
   for (int i = 0; i < L.nh; i++) {
-    sm[L.range_lo + i] = m.range_lo[i];
-    sm[L.range_hi + i] = m.range_hi[i];
-    si[L.i_hinge_body + i] = (short)m.hinge_body[i];
-    si[L.i_limited + i] = (short)m.limited[i];
+    sm[L.o.range_lo + i] = m.range_lo[i];
+    sm[L.o.range_hi + i] = m.range_hi[i];
+    si[L.o.i_hinge_body + i] = (short)m.hinge_body[i];
+    si[L.o.i_limited + i] = (short)m.limited[i];
   }
   {
     const IkTree tree = make_ik_tree(m);
-    for (int l = 0; l < 4; l++) for (int a2 = 0; a2 < 8; a2++) si[L.i_tree_limb + l * 8 + a2] = (short)tree.limb[l][a2];
-    for (int t2 = 0; t2 < 10; t2++) si[L.i_tree_trunk + t2] = (short)tree.trunk[t2];
-    reinterpret_cast<int*>(sw + L.w_tr_cnt)[1] = -1;
-    reinterpret_cast<int*>(sw + L.w_tr_cnt)[3] = -1;
+    for (int l = 0; l < 4; l++) for (int a2 = 0; a2 < 8; a2++) si[L.o.i_tree_limb + l * 8 + a2] = (short)tree.limb[l][a2];
+    for (int t2 = 0; t2 < 10; t2++) si[L.o.i_tree_trunk + t2] = (short)tree.trunk[t2];
+    reinterpret_cast<int*>(sw + L.o.w_tr_cnt)[1] = -1;
+    reinterpret_cast<int*>(sw + L.o.w_tr_cnt)[3] = -1;
   }
   for (int i = 0; i < L.nhum; i++) {
-    sm[L.scale + i] = ts.scale[i];
-    for (int a = 0; a < 3; a++) sm[L.pos_off + 3 * i + a] = ts.pos_off[i][a];
-    for (int a = 0; a < 4; a++) sm[L.quat_off + 4 * i + a] = ts.quat_off[i][a];
-    si[L.i_is_foot + i] = (short)ts.is_foot[i];
+    sm[L.o.scale + i] = ts.scale[i];
+    for (int a = 0; a < 3; a++) sm[L.o.pos_off + 3 * i + a] = ts.pos_off[i][a];
+    for (int a = 0; a < 4; a++) sm[L.o.quat_off + 4 * i + a] = ts.quat_off[i][a];
+    si[L.o.i_is_foot + i] = (short)ts.is_foot[i];
   }
   for (int s = 0; s < 2; s++) {
     uint32_t* dst = L.g_items[s] >= 0 ? reinterpret_cast<uint32_t*>(img.data()) + L.g_items[s] : sw + L.w_items[s];
     for (size_t i = 0; i < sch.padded[s].size(); i++) dst[i] = sch.padded[s][i];
     for (int k = 0; k < L.K[s]; k++) {
-      si[L.i_task_body[s] + k] = (short)ts.task_body[s][k];
-      si[L.i_task_human[s] + k] = (short)ts.task_human[s][k];
-      sm[L.wpos[s] + k] = ts.w_pos[s][k];
-      sm[L.wrot[s] + k] = ts.w_rot[s][k];
-      for (int d = 0; d < nv; d++) si[L.i_pair_index[s] + k * nv + d] = (short)ts.pair_index[s][k][d];
+      si[L.o.i_task_body[s] + k] = (short)ts.task_body[s][k];
+      si[L.o.i_task_human[s] + k] = (short)ts.task_human[s][k];
+      sm[L.o.wpos[s] + k] = ts.w_pos[s][k];
+      sm[L.o.wrot[s] + k] = ts.w_rot[s][k];
+      for (int d = 0; d < nv; d++) si[L.o.i_pair_index[s] + k * L.nvp + d] = (short)ts.pair_index[s][k][d];
     }
     // per (task, dof) pair, everything the Jacobian-column phase looks up, packed so that it is two
     // independent 16-bit reads instead of a chain of four: [3:0] task, [9:4] dof, [15:10] task body; hinge body
     for (int p = 0; p < L.P[s]; p++) {
       const int k = ts.pair_task[s][p], d = ts.pair_dof[s][p];
-      si[L.i_pair_task[s] + p] = (short)(unsigned short)(k | (d << 4) | (ts.task_body[s][k] << 10));
-      si[L.i_pair_dof[s] + p] = (short)(d >= 6 ? m.hinge_body[d - 6] : 0);
+      si[L.o.i_pair_task[s] + p] = (short)(unsigned short)(k | (d << 4) | (ts.task_body[s][k] << 10));
+      si[L.o.i_pair_dof[s] + p] = (short)(d >= 6 ? m.hinge_body[d - 6] : 0);
     }
   }
   return img;

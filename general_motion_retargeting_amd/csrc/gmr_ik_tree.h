@@ -42,23 +42,24 @@ __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
 struct TreeState { unsigned long long lower, upper; };
 
 // All four wavefronts call this together.  Returns GMR_STATUS_* (the same value in every wavefront);
-// the solution is left in sm[L.x].  Three workgroup barriers per pivoting round (two when no bound is
+// the solution is left in sm[L.o.x].  Three workgroup barriers per pivoting round (two when no bound is
 // active): the trunk system is summed, factorised and solved redundantly by every wavefront, so
 // the only exchanges are the limbs' Schur contributions, the solution x and the violation sets.
-__device__ __forceinline__ int solve_qp_tree(const IkLayout& L, double* sm, uint32_t* sw, const short* si, int wave,
+template <class LT>
+__device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* sw, const short* si, int wave,
                                              int lane, TreeState& bs, Prof& pr) {
-  const int n = L.nv, ldh = L.ldh;
-  const double* H = sm + L.H;
-  const short* limb = si + L.i_tree_limb + wave * TR_NL;     // dof of limb row a, or -1
-  const short* trunk = si + L.i_tree_trunk;                  // dof of trunk row t, or -1
-  double* xs = sm + L.x;
-  const double* los = sm + L.lo;
-  const double* his = sm + L.hi;
-  double* Spart = sm + L.tr_spart;                           // [4][TR_NT][TR_NT]
-  double* rpart = sm + L.tr_rpart;                           // [4][TR_NT]
-  double* Lscr = sm + L.Kt + wave * TR_NV * TR_LD;           // this wavefront's transpose scratch
+  const int n = L.nv, ldh = L.o.ldh;
+  const double* H = sm + L.o.H;
+  const short* limb = si + L.o.i_tree_limb + wave * TR_NL;     // dof of limb row a, or -1
+  const short* trunk = si + L.o.i_tree_trunk;                  // dof of trunk row t, or -1
+  double* xs = sm + L.o.x;
+  const double* los = sm + L.o.lo;
+  const double* his = sm + L.o.hi;
+  double* Spart = sm + L.o.tr_spart;                           // [4][TR_NT][TR_NT]
+  double* rpart = sm + L.o.tr_rpart;                           // [4][TR_NT]
+  double* Lscr = sm + L.o.Kt + wave * TR_NV * TR_LD;           // this wavefront's transpose scratch
   // violation sets of a round, double-buffered: {to_lower, to_upper, release, flags} x 2
-  unsigned long long* vset = reinterpret_cast<unsigned long long*>(sw + L.w_tr_mask);
+  unsigned long long* vset = reinterpret_cast<unsigned long long*>(sw + L.o.w_tr_mask);
 
   const bool is_limb = lane < TR_NL, is_trunk = lane >= TR_NL && lane < TR_NV;
   const int a = lane, t = lane - TR_NL;
@@ -66,9 +67,9 @@ __device__ __forceinline__ int solve_qp_tree(const IkLayout& L, double* sm, uint
   const bool row = dof >= 0;                                 // this lane holds a real row
   const bool own = row && (is_limb || wave == 0);            // ... and reports the variable's violations
   const double lo = row ? los[dof] : 0.0, hi = row ? his[dof] : 0.0;
-  const double ci = row ? (sm + L.c)[dof] : 0.0;
+  const double ci = row ? (sm + L.o.c)[dof] : 0.0;
   const double* Hrow = H + (row ? dof : 0) * ldh;
-  double cabs = lane < n ? fabs((sm + L.c)[lane]) : 0.0;
+  double cabs = lane < n ? fabs((sm + L.o.c)[lane]) : 0.0;
   const double dual_tol = 1e-13 * (1.0 + wave_max(cabs));
   const double ptol_lo = 1e-12 * (1.0 + fabs(lo)), ptol_hi = 1e-12 * (1.0 + fabs(hi));
   // column dofs of the local matrix (wave-uniform): limb columns then trunk columns

@@ -107,16 +107,17 @@ int main(int argc, char** argv) {
     gmr::IkLayout L = gmr::make_ik_layout(m, ts, sch, nw);
     CHECK(L.smem_bytes > 0 && L.smem_bytes <= 160 * 1024 - 1024, "LDS bytes %d", L.smem_bytes);
     CHECK(L.nvp >= nv && (L.nvp == 28 || L.nvp == 32 || L.nvp == 36 || L.nvp == 48), "nvp");
-    CHECK((L.ldh & 1) == 1 && L.ldh > nv, "odd H row stride");
+    CHECK(L.nb <= L.o.cap.nb && L.nh <= L.o.cap.nh && L.nhum <= L.o.cap.nhum && L.K[0] <= L.o.cap.k && L.P[0] <= L.o.cap.p && L.P[1] <= L.o.cap.p, "class capacities");
+    CHECK((L.o.ldh & 1) == 1 && L.o.ldh > nv, "odd H row stride");
     std::vector<char> img = gmr::make_ik_image(m, ts, sch, L);
     CHECK((int)img.size() >= L.smem_bytes && img.size() % 16 == 0, "image size");
     CHECK(L.tree_ok == ((nw == 4 && tr.ok) ? 1 : 0), "tree flag");
     {   // the QP transpose scratch may alias the assembly scratch, never H / c / x / lo / hi
       const int need = std::max(L.nvp * (L.nvp + 1), nw == 4 ? 4 * 18 * 19 : 0);
-      CHECK(L.Kt >= L.e && L.Kt + need <= L.H, "Kt [%d,%d) overlaps H at %d", L.Kt, L.Kt + need, L.H);
-      CHECK(L.H + nv * L.ldh <= L.c, "H overlaps c");
+      CHECK(L.o.Kt >= L.o.e && L.o.Kt + need <= L.o.H, "Kt [%d,%d) overlaps H at %d", L.o.Kt, L.o.Kt + need, L.o.H);
+      CHECK(L.o.H + nv * L.o.ldh <= L.o.c, "H overlaps c");
     }
-    lds[nw == 4] = L.smem_bytes; nd[nw == 4] = L.n_double; nwd[nw == 4] = L.n_word;
+    lds[nw == 4] = L.smem_bytes; nd[nw == 4] = L.o.n_double; nwd[nw == 4] = (L.smem_bytes - L.o.n_double * 8 - L.o.n_short * 2) / 4;
   }
   std::printf("ok nv=%d tree=%d limbs=%d trunk=%d lds1=%d (%d doubles, %d words) lds4=%d (%d doubles, %d words)\n", nv, (int)tr.ok, nlimb, tr.nt,
               lds[0], nd[0], nwd[0], lds[1], nd[1], nwd[1]);
