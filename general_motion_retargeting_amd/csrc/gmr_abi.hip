@@ -264,7 +264,7 @@ int gmr_retarget_streams_dev(gmr_solver_t* s, int S, int T, const double* d_q0, 
   if (!d_q0 || !d_human || !d_q_out || !d_nsolve || !d_status) return fail(GMR_ERR_ARG, "null device buffer");
   // few streams: 4 waves per stream (helpers share the wide assembly phases, shorter per-frame
   // latency); many streams: 1 wave per stream (more streams resident, more frames per second)
-  const bool wide = s->force_waves ? s->force_waves == 4 : S <= GMR_HELPER_MAX_STREAMS;
+  const bool wide = s->layout4.tree_ok && (s->force_waves ? s->force_waves == 4 : S <= GMR_HELPER_MAX_STREAMS);
   HIP_TRY(gmr_launch_ik_streams(wide ? s->d_image4 : s->d_image, wide ? &s->layout4 : &s->layout, &s->params, S, T,
                                 d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, (hipStream_t)stream, nullptr));
   return GMR_OK;
@@ -274,7 +274,7 @@ int gmr_retarget_streams_dev(gmr_solver_t* s, int S, int T, const double* d_q0, 
 // diagnostic builds only (tools/phase_profile.py): per-stream phase cycle counters
 int gmr_retarget_streams_prof(gmr_solver_t* s, int S, int T, const double* d_q0, const double* d_human, int flags,
                               double* d_q_out, int32_t* d_nsolve, int32_t* d_status, unsigned long long* d_prof) {
-  const bool wide = s->force_waves ? s->force_waves == 4 : S <= GMR_HELPER_MAX_STREAMS;
+  const bool wide = s->layout4.tree_ok && (s->force_waves ? s->force_waves == 4 : S <= GMR_HELPER_MAX_STREAMS);
   HIP_TRY(gmr_launch_ik_streams(wide ? s->d_image4 : s->d_image, wide ? &s->layout4 : &s->layout, &s->params, S, T,
                                 d_q0, d_human, nullptr, flags, d_q_out, d_nsolve, d_status, nullptr, d_prof));
   return GMR_OK;

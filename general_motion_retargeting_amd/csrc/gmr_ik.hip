@@ -483,7 +483,7 @@ __device__ __forceinline__ void helper_loop(const LT& L, double* sm, const uint3
     PROF_BEGIN(hp);
     __syncthreads();                      // B3
     PROF_END(hp, PH_JLOG);                // wait at B3
-    if (L.tree_ok) (void)solve_qp_tree(L, sm, const_cast<uint32_t*>(sw), si, wave, lane, bs, hp);
+    (void)solve_qp_tree(L, sm, const_cast<uint32_t*>(sw), si, wave, lane, bs, hp);   // NW > 1 is only launched for robots that decompose
   }
 }
 
@@ -751,8 +751,7 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
 #endif
     return;
   }
-  const double damping = P.damping, lm_damping = P.lm_damping, tol = P.tol, limit_gain = P.limit_gain;
-  const double ground_offset = P.ground_offset, dt = P.dt;
+  const double* prm = sm + L.o.params;   // damping, lm_damping, tol, limit_gain, ground_offset, dt: read where used
   const int max_iter = P.max_iter, human_root = P.human_root;
   const int use0 = P.use0, use1 = P.use1;
 
@@ -785,7 +784,7 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
     WSYNC();
     int ns0 = 0, ns1 = 0;
     if (stat == GMR_STATUS_OK) {
-      preprocess_wave<NW>(L, sm, is_foot, human_root, ground_offset, flags, lane, pr);
+      preprocess_wave<NW>(L, sm, is_foot, human_root, prm[4], flags, lane, pr);
       for (int stage = 0; stage < 2; stage++) {
         if (!(stage == 0 ? use0 : use1)) continue;
         const StageTabs tb = {si + L.o.i_task_body[stage], si + L.o.i_task_human[stage], si + L.o.i_pair_task[stage],
@@ -801,22 +800,22 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
         double curr = errors_wave<NW>(L, sm, tb.task_body, tb.task_human, K, lane, pr);
         int nsol = 0, num_iter = 0;
         for (;;) {
-          build_qp_main<NW>(L, sm, stage, tb, hinge_body, limited, ctl, damping, lm_damping, limit_gain, lane, pr);
+          build_qp_main<NW>(L, sm, stage, tb, hinge_body, limited, ctl, prm[0], prm[1], prm[3], lane, pr);
           PROF_COUNT(pr, PH_NSOLVE);
           int rc;
-          if (NW > 1 && L.tree_ok) {
+          if (NW > 1) {   // the 4-wavefront shape is only launched for robots that decompose (gmr_abi.hip)
             PROF_COUNT(pr, PH_NFACT);
             rc = solve_qp_tree(L, sm, sw, si, 0, lane, tree_state, pr);   // helpers joined after barrier B3
           } else {
             rc = solve_qp_regs<NVP, NW>(L, sm, lane, qp_state, pr);
           }
           if (rc != GMR_STATUS_OK) { stat = rc; break; }
-          integrate_wave<NW>(L, sm, dt, lane, pr);
+          integrate_wave<NW>(L, sm, prm[5], lane, pr);
           fk_wave<NW>(L, sm, hop, depth, body_hinge, lane, pr);
           double next = errors_wave<NW>(L, sm, tb.task_body, tb.task_human, K, lane, pr);
           nsol++;
           if (nsol > 1) num_iter++;
-          if (!(curr - next > tol && num_iter < max_iter)) break;
+          if (!(curr - next > prm[2] && num_iter < max_iter)) break;
           curr = next;
         }
         if (stage == 0) ns0 = nsol; else ns1 = nsol;

@@ -34,6 +34,7 @@ struct IkOffsets {
   int body_pos, body_quat, axis, range_lo, range_hi, scale, pos_off, quat_off;
   int wpos[2], wrot[2];
   int q, xa, xb, xaxis, raw, tgt, e, eaux, we, M, Jw, cpart, H, Kt, c, x, lo, hi, scal, tr_spart, tr_rpart;
+  int params;                    // damping, lm_damping, tol, limit_gain, ground_offset, dt (read where used: not in SGPRs)
   int n_double;
   // offsets in shorts (after the doubles)
   int i_hop, i_depth, i_body_hinge, i_hinge_body, i_limited, i_is_foot, i_tree_limb, i_tree_trunk;
@@ -55,6 +56,7 @@ constexpr IkOffsets ik_offsets(int nvp, int nw) {
   int o = 0;
   L.body_pos = o; o += 3 * cp.nb; L.body_quat = o; o += 4 * cp.nb; L.axis = o; o += 3 * cp.nb;
   L.range_lo = o; o += cp.nh; L.range_hi = o; o += cp.nh;
+  L.params = o; o += 6;
   L.scale = o; o += cp.nhum; L.pos_off = o; o += 3 * cp.nhum; L.quat_off = o; o += 4 * cp.nhum;
   for (int s = 0; s < 2; s++) { L.wpos[s] = o; o += cp.k; L.wrot[s] = o; o += cp.k; }
   L.q = o; o += 7 + cp.nh + 1;
@@ -399,6 +401,10 @@ inline std::vector<char> make_ik_image(const gmr_model_t& m, const gmr_taskset_t
     for (int t2 = 0; t2 < 10; t2++) si[L.o.i_tree_trunk + t2] = (short)tree.trunk[t2];
     reinterpret_cast<int*>(sw + L.o.w_tr_cnt)[1] = -1;
     reinterpret_cast<int*>(sw + L.o.w_tr_cnt)[3] = -1;
+  }
+  {
+    const double prm[6] = {ts.damping, ts.lm_damping, ts.tol, ts.limit_gain, ts.ground_offset, m.timestep};
+    for (int i = 0; i < 6; i++) sm[L.o.params + i] = prm[i];
   }
   for (int i = 0; i < L.nhum; i++) {
     sm[L.o.scale + i] = ts.scale[i];

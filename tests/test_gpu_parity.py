@@ -393,7 +393,8 @@ def _synthetic_robot(tmp_path, name, chains, tasks):
 @pytest.mark.parametrize("topology", ["biped_no_arms", "five_limbs_head_in_trunk", "hand_with_fingers", "too_wide_for_tree"])
 def test_generic_topologies(hip, oracle, tmp_path, topology):
     """Robots the shipped set does not contain: fewer / more limbs, limbs that branch (the arm becomes
-    trunk), and one the tree solver must refuse (dense fallback).  Both launch shapes against the oracle."""
+    trunk), and one the tree solver must refuse (that robot always runs the 1-wavefront shape, whatever is
+    requested).  Both launch-shape requests against the oracle."""
     from general_motion_retargeting_amd import synth
     if topology == "biped_no_arms":
         chains = {"l": ("base", 6, "0 0.1 0"), "r": ("base", 6, "0 -0.1 0")}
