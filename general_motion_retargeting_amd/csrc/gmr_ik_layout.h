@@ -108,6 +108,7 @@ constexpr IkOffsets ik_offsets(int nvp, int nw) {
 // what varies per robot inside a class: passed by value to the kernel (the only layout state in SGPRs)
 struct IkDims {
   int nb, nh, nq, nv, nhum, nhop, tree_ok;
+  int tree_small;                // limbs <= 7 dofs and trunk <= 9: the <7, 9> instance of the tree solver applies
   int K[2], P[2], ntrip[2], nlanes, pair_lanes;
   int w_items[2];                // NW > 1: word offset of a stage's schedule from the start of the words
   int g_items[2];                // NW == 1: the schedule stays in the global image at these word offsets; else -1
@@ -329,6 +330,11 @@ inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, co
   const IkTree tree = make_ik_tree(m);
   L.tree_ok = (nw == 4 && tree.ok) ? 1 : 0;
   L.tree_nt = tree.nt;
+  {
+    int maxlimb = 0;
+    for (auto& l : tree.limb) { int n = 0; for (int d : l) n += d >= 0; maxlimb = std::max(maxlimb, n); }
+    L.tree_small = (L.tree_ok && maxlimb <= 7 && tree.nt <= 9) ? 1 : 0;
+  }
   L.nb = m.nbody; L.nh = m.nhinge; L.nq = m.nq; L.nv = m.nv; L.nhum = ts.nhuman;
   L.nvp = ik_size_class(m, ts);
   int maxd = 1;

@@ -22,10 +22,9 @@
 
 namespace gmr {
 
-constexpr int TR_NL = 8;             // limb rows per wavefront
-constexpr int TR_NT = 10;            // trunk rows
-constexpr int TR_NV = TR_NL + TR_NT; // local matrix order
-constexpr int TR_LD = TR_NV + 1;     // row stride of the LDS transpose scratch
+constexpr int TR_MAX_NL = 8;                     // capacity: limb rows per wavefront (LDS tables, scratch strides)
+constexpr int TR_MAX_NT = 10;                    // capacity: trunk rows
+constexpr int TR_LD = TR_MAX_NL + TR_MAX_NT + 1; // row stride of the LDS transpose scratch
 
 __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
   unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
@@ -45,19 +44,22 @@ struct TreeState { unsigned long long lower, upper; };
 // the solution is left in sm[L.o.x].  Three workgroup barriers per pivoting round (two when no bound is
 // active): the trunk system is summed, factorised and solved redundantly by every wavefront, so
 // the only exchanges are the limbs' Schur contributions, the solution x and the violation sets.
-template <class LT>
+// TR_NL / TR_NT: rows actually eliminated (limbs <= TR_NL dofs, trunk <= TR_NT): the pivots are unrolled, so a
+// robot with 7-dof limbs and a 9-dof trunk (every shipped one) runs the <7, 9> instance: 16 instead of 18 pivots.
+template <int TR_NL, int TR_NT, class LT>
 __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* sw, const short* si, int wave,
                                              int lane, TreeState& bs, Prof& pr) {
+  constexpr int TR_NV = TR_NL + TR_NT;             // local matrix order
   const int n = L.nv, ldh = L.o.ldh;
   const double* H = sm + L.o.H;
-  const short* limb = si + L.o.i_tree_limb + wave * TR_NL;     // dof of limb row a, or -1
+  const short* limb = si + L.o.i_tree_limb + wave * TR_MAX_NL;     // dof of limb row a, or -1
   const short* trunk = si + L.o.i_tree_trunk;                  // dof of trunk row t, or -1
   double* xs = sm + L.o.x;
   const double* los = sm + L.o.lo;
   const double* his = sm + L.o.hi;
   double* Spart = sm + L.o.tr_spart;                           // [4][TR_NT][TR_NT]
   double* rpart = sm + L.o.tr_rpart;                           // [4][TR_NT]
-  double* Lscr = sm + L.o.Kt + wave * TR_NV * TR_LD;           // this wavefront's transpose scratch
+  double* Lscr = sm + L.o.Kt + wave * (TR_MAX_NL + TR_MAX_NT) * TR_LD;           // this wavefront's transpose scratch
   // violation sets of a round, double-buffered: {to_lower, to_upper, release, flags} x 2
   unsigned long long* vset = reinterpret_cast<unsigned long long*>(sw + L.o.w_tr_mask);
 
@@ -142,8 +144,8 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
     // ---- (3) publish the Schur contribution; park L_l / Y_l for the transposed reads --------------
     if (is_trunk) {
 #pragma unroll
-      for (int u = 0; u < TR_NT; u++) Spart[(wave * TR_NT + t) * TR_NT + u] = r[TR_NL + u];
-      rpart[wave * TR_NT + t] = b;
+      for (int u = 0; u < TR_NT; u++) Spart[(wave * TR_MAX_NT + t) * TR_MAX_NT + u] = r[TR_NL + u];
+      rpart[wave * TR_MAX_NT + t] = b;
     }
     if (lane < TR_NV) {
 #pragma unroll
@@ -171,10 +173,10 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
         for (int u = 0; u < TR_NT; u++) {
           const int cd = cdof[TR_NL + u];
           hv[u] = Hrow[cd >= 0 ? cd : 0];
-          const double* q0 = Spart + tt * TR_NT + u;
-          sp[u] = (q0[0] + q0[TR_NT * TR_NT]) + (q0[2 * TR_NT * TR_NT] + q0[3 * TR_NT * TR_NT]);
+          const double* q0 = Spart + tt * TR_MAX_NT + u;
+          sp[u] = (q0[0] + q0[TR_MAX_NT * TR_MAX_NT]) + (q0[2 * TR_MAX_NT * TR_MAX_NT] + q0[3 * TR_MAX_NT * TR_MAX_NT]);
         }
-        const double rp = (rpart[tt] + rpart[TR_NT + tt]) + (rpart[2 * TR_NT + tt] + rpart[3 * TR_NT + tt]);
+        const double rp = (rpart[tt] + rpart[TR_MAX_NT + tt]) + (rpart[2 * TR_MAX_NT + tt] + rpart[3 * TR_MAX_NT + tt]);
         const bool live = is_trunk && row && !self_fixed;
 #pragma unroll
         for (int u = 0; u < TR_NT; u++) {
