@@ -15,7 +15,7 @@ for grp in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_WAVES SQ_BUSY_CYCLES SQ_
 done
 cd $R
 python tools/collect_traffic.py $V $O/pmc_${V}_fetch $O/pmc_${V}_write $O/pmc_${V}_sq > $O/traffic_$V.json || exit 4
-python tools/phase_profile.py > $O/phase_$V.txt 2>&1 || exit 5
-python tools/latency_probe.py > $O/latency_$V.json 2>&1 || exit 6
-python tools/shape_sweep.py > $O/shape_sweep_$V.txt 2>&1 || exit 7
+python tools/phase_profile.py > $O/phase_$V.txt 2>/dev/null || exit 5
+python tools/latency_probe.py > $O/latency_$V.json 2>/dev/null || exit 6
+python tools/shape_sweep.py > $O/shape_sweep_$V.txt 2>/dev/null || exit 7
 echo done
