@@ -17,7 +17,7 @@
 // state of a variable lives in the lane that owns its row.  Five workgroup barriers per pivoting round.
 //
 // Used by the latency shape (NW = 4) when the robot decomposes into <= 4 limbs of <= 8 dofs and a
-// trunk of <= 10 (all 8 shipped robots do); otherwise the dense solver runs on the main wavefront.
+// trunk of <= 10 (all 8 shipped robots do); other robots always run the 1-wavefront kernel (dense solver).
 #pragma once
 
 namespace gmr {
