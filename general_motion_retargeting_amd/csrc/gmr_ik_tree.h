@@ -11,10 +11,11 @@
 // Each wavefront eliminates ONE limb (Cholesky of D_l, Y_l = B_l L_l^-T, its Schur contribution
 // -Y_l Y_l^T and the forward-substituted right-hand side) with its rows in registers exactly like the
 // dense solver, but on an 18-column local matrix: 108 instead of 630 (pivot, column) updates and 8
-// instead of 36 pivots on the critical path, the four limbs side by side.  The main wavefront then
-// factors the 10x10 trunk Schur complement, solves it, and the limbs back-substitute in parallel.
-// Bounds are handled by the same block principal pivoting as the dense solver (gmr_ik.hip); the bound
-// state of a variable lives in the lane that owns its row.  Five workgroup barriers per pivoting round.
+// instead of 36 pivots on the critical path, the four limbs side by side.  Every wavefront then sums,
+// factors and solves the trunk Schur complement redundantly (no exchange of x_T), and the limbs
+// back-substitute in parallel.  Bounds are handled by the same block principal pivoting as the dense solver
+// (gmr_ik.hip) on wave-uniform bound masks kept identically in all wavefronts: two to three workgroup
+// barriers per pivoting round (Schur parts; x when a bound is active; violation sets).
 //
 // Used by the latency shape (NW = 4) when the robot decomposes into <= 4 limbs of <= 8 dofs and a
 // trunk of <= 10 (all 8 shipped robots do); other robots always run the 1-wavefront kernel (dense solver).
