@@ -475,3 +475,49 @@ def test_library_and_torch_share_one_hip_runtime():
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "one runtime:" in r.stdout
+
+
+@pytest.mark.gpu
+def test_robot_promoted_to_larger_size_class(hip, oracle, tmp_path):
+    """LDS offsets are compile-time constants of a size class (csrc/gmr_ik_layout.h: NVP 28/32/36/48 with body /
+    task / pair capacities).  A robot with few dofs but more bodies than its class holds (nv = 16 -> class 28,
+    capacity 34 bodies; here 41 bodies, most of them jointless) must move to a class that holds it (48) and still
+    match the oracle in both launch-shape requests."""
+    from general_motion_retargeting_amd import synth
+    from general_motion_retargeting_amd.ik_config import build_task_tables, pack_model, pack_taskset
+    from general_motion_retargeting_amd.mjcf import compile_mjcf
+    axes = ["1 0 0", "0 1 0", "0 0 1"]
+
+    def leg(prefix, y):
+        s, e = "", ""
+        for i in range(5):
+            s += (f'<body name="{prefix}{i}" pos="{"0 %s -0.05" % y if i == 0 else "0.01 0 -0.1"}">'
+                  f'<joint name="{prefix}j{i}" axis="{axes[i % 3]}" range="-1.2 1.2"/>')
+            s += "".join(f'<body name="{prefix}{i}_m{k}" pos="0.0{k + 1} 0.01 0"/>' for k in range(3))   # jointless
+            e += "</body>"
+        return s + e
+    xml = ('<mujoco model="many_bodies"><compiler angle="radian"/><worldbody><body name="base" pos="0 0 1"><freejoint/>'
+           + leg("l", 0.1) + leg("r", -0.1) + '</body></worldbody></mujoco>')
+    p = tmp_path / "many_bodies.xml"
+    p.write_text(xml)
+    model = compile_mjcf(str(p))
+    assert model.nv == 16 and model.nbody == 41
+    tasks = [("base", 100, 10), ("l2", 0, 10), ("l4", 50, 10), ("r2", 0, 10), ("r4", 50, 10), ("l4_m2", 10, 0)]
+    names = [f"h{i}" for i in range(len(tasks))]
+    tbl1 = {f: [h, wp, wr, [0.01, 0, 0], [1, 0, 0, 0]] for (f, wp, wr), h in zip(tasks, names)}
+    tbl2 = {f: [h, wp + 1, max(wr, 1), [0, 0, 0], [1, 0, 0, 0]] for (f, wp, wr), h in zip(tasks, names)}
+    cfg = {"robot_root_name": "base", "human_root_name": "h0", "ground_height": 0.0, "human_height_assumption": 1.8,
+           "use_ik_match_table1": True, "use_ik_match_table2": True, "human_scale_table": {n: 0.9 for n in names},
+           "ik_match_table1": tbl1, "ik_match_table2": tbl2}
+    tt = build_task_tables(cfg, 1.7)
+    mb, ts = pack_model(model), pack_taskset(model, tt)
+    human, q0 = synth.make_streams(model, tt, 4, 6, seed=77)
+    q_o, ns_o, st_o = oracle.retarget_streams(mb, ts, q0, human)
+    assert (st_o == 0).all()
+    sol = hip.Solver(mb, ts)
+    for waves in (0, 1, 4):
+        sol.set_waves(waves)
+        q_h, ns_h, st_h = sol.retarget_streams(q0, human)
+        assert (st_h == 0).all() and np.array_equal(ns_h, ns_o), waves
+        joint, pos, rot = _compare(q_h, q_o)
+        assert joint <= 1e-8 and pos <= 1e-8 and rot <= 1e-8, (waves, joint, pos, rot)
