@@ -199,4 +199,56 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+// Reductions over the 16-lane DPP rows (v_mov_b32 row_shr: a few cycles per step instead of a 70-cycle
+// ds_bpermute round trip).  The IK kernel reduces over tasks (<= 16: row 0) and over dofs (<= 48: rows 0..2).
+__device__ __forceinline__ double dpp_row_shr(double v, double fill, int n) {   // lane i <- lane i - n of its row, `fill` if none
+  union { double d; int i[2]; } a, f, r;
+  a.d = v; f.d = fill;
+  // dpp_ctrl 0x110 | n = row_shr:n; bound_ctrl = false keeps `old` (= fill) where the source lane does not exist
+  switch (n) {
+    case 1: r.i[0] = __builtin_amdgcn_update_dpp(f.i[0], a.i[0], 0x111, 0xf, 0xf, false); r.i[1] = __builtin_amdgcn_update_dpp(f.i[1], a.i[1], 0x111, 0xf, 0xf, false); break;
+    case 2: r.i[0] = __builtin_amdgcn_update_dpp(f.i[0], a.i[0], 0x112, 0xf, 0xf, false); r.i[1] = __builtin_amdgcn_update_dpp(f.i[1], a.i[1], 0x112, 0xf, 0xf, false); break;
+    case 4: r.i[0] = __builtin_amdgcn_update_dpp(f.i[0], a.i[0], 0x114, 0xf, 0xf, false); r.i[1] = __builtin_amdgcn_update_dpp(f.i[1], a.i[1], 0x114, 0xf, 0xf, false); break;
+    default: r.i[0] = __builtin_amdgcn_update_dpp(f.i[0], a.i[0], 0x118, 0xf, 0xf, false); r.i[1] = __builtin_amdgcn_update_dpp(f.i[1], a.i[1], 0x118, 0xf, 0xf, false); break;
+  }
+  return r.d;
+}
+// sum of lanes 0..15 (lanes 16..63 must hold 0 or are ignored), the same value in every lane
+__device__ __forceinline__ double row0_sum(double v) {
+  v += dpp_row_shr(v, 0.0, 1);
+  v += dpp_row_shr(v, 0.0, 2);
+  v += dpp_row_shr(v, 0.0, 4);
+  v += dpp_row_shr(v, 0.0, 8);
+  union { double d; int i[2]; } a, r;
+  a.d = v;
+  r.i[0] = __builtin_amdgcn_readlane(a.i[0], 15);
+  r.i[1] = __builtin_amdgcn_readlane(a.i[1], 15);
+  return r.d;
+}
+// min over lanes 0..15
+__device__ __forceinline__ double row0_min(double v) {
+  v = fmin(v, dpp_row_shr(v, v, 1));
+  v = fmin(v, dpp_row_shr(v, v, 2));
+  v = fmin(v, dpp_row_shr(v, v, 4));
+  v = fmin(v, dpp_row_shr(v, v, 8));
+  union { double d; int i[2]; } a, r;
+  a.d = v;
+  r.i[0] = __builtin_amdgcn_readlane(a.i[0], 15);
+  r.i[1] = __builtin_amdgcn_readlane(a.i[1], 15);
+  return r.d;
+}
+// max over lanes 0..47
+__device__ __forceinline__ double rows3_max(double v) {
+  v = fmax(v, dpp_row_shr(v, v, 1));
+  v = fmax(v, dpp_row_shr(v, v, 2));
+  v = fmax(v, dpp_row_shr(v, v, 4));
+  v = fmax(v, dpp_row_shr(v, v, 8));
+  union { double d; int i[2]; } a, r0, r1, r2;
+  a.d = v;
+  r0.i[0] = __builtin_amdgcn_readlane(a.i[0], 15); r0.i[1] = __builtin_amdgcn_readlane(a.i[1], 15);
+  r1.i[0] = __builtin_amdgcn_readlane(a.i[0], 31); r1.i[1] = __builtin_amdgcn_readlane(a.i[1], 31);
+  r2.i[0] = __builtin_amdgcn_readlane(a.i[0], 47); r2.i[1] = __builtin_amdgcn_readlane(a.i[1], 47);
+  return fmax(fmax(r0.d, r1.d), r2.d);
+}
+
 }  // namespace gmr

@@ -179,7 +179,7 @@ __device__ __forceinline__ double errors_wave(const LT& L, double* sm, const sho
     double* ao = sm + L.o.eaux + 3 * lane;     // a, sin|w|, cos|w|: reused by the Jl^-1 phase
     ao[0] = aux[0]; ao[1] = aux[1]; ao[2] = aux[2];
   }
-  ss = wave_sum(ss);
+  ss = row0_sum(ss);                 // tasks live in lanes 0..K-1, K <= 16
   WSYNC();
   PROF_END(pr, PH_ERR);
   return sqrt(ss);
@@ -224,7 +224,7 @@ __device__ __forceinline__ double jlog_phase(const LT& L, double* sm, int stage,
       mu += v * v;
     }
   }
-  mu = lm_damping * wave_sum(mu);
+  mu = lm_damping * row0_sum(mu);
   WSYNC();
   PROF_END(pr, PH_JLOG);
   return mu;
@@ -508,7 +508,7 @@ __device__ __forceinline__ int solve_qp_regs(const LT& L, double* sm, int lane, 
   const double ci = act ? (sm + L.o.c)[lane] : 0.0;
   const double* Hrow = H + (act ? lane : 0) * ldh;
   if (!act || (st < 0 && !(lo > -INFINITY)) || (st > 0 && !(hi < INFINITY))) st = 0;
-  const double dual_tol = 1e-13 * (1.0 + wave_max(fabs(ci)));
+  const double dual_tol = 1e-13 * (1.0 + rows3_max(fabs(ci)));   // dofs live in lanes 0..nv-1, nv <= 48
   const double ptol_lo = 1e-12 * (1.0 + fabs(lo)), ptol_hi = 1e-12 * (1.0 + fabs(hi));
   int pcount = 3, ninf_best = NVP + 1;
   for (int it = 0; it < 100; it++) {
@@ -693,7 +693,7 @@ __device__ __forceinline__ void preprocess_wave(const LT& L, double* sm, const s
     if (is_foot[lane] && p.x == p.x) z = p.z;
   }
   if (flags & GMR_FLAG_OFFSET_TO_GROUND) {
-    double lowest = wave_min(z);
+    double lowest = row0_min(z);      // human bodies live in lanes 0..nhum-1, nhum <= 16
     p.z = p.z - lowest + ground_offset;
   }
   if (on) {

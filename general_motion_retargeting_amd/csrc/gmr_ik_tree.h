@@ -73,7 +73,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
   const double ci = row ? (sm + L.o.c)[dof] : 0.0;
   const double* Hrow = H + (row ? dof : 0) * ldh;
   double cabs = lane < n ? fabs((sm + L.o.c)[lane]) : 0.0;
-  const double dual_tol = 1e-13 * (1.0 + wave_max(cabs));
+  const double dual_tol = 1e-13 * (1.0 + rows3_max(cabs));
   const double ptol_lo = 1e-12 * (1.0 + fabs(lo)), ptol_hi = 1e-12 * (1.0 + fabs(hi));
   // column dofs of the local matrix (wave-uniform): limb columns then trunk columns
   int cdof[TR_NV];
