@@ -213,6 +213,14 @@ __device__ __forceinline__ double dpp_row_shr(double v, double fill, int n) {   
   }
   return r.d;
 }
+// value of the neighbouring lane (lane ^ 1): DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ double dpp_swap_pairs(double v) {
+  union { double d; int i[2]; } a, r;
+  a.d = v;
+  r.i[0] = __builtin_amdgcn_update_dpp(a.i[0], a.i[0], 0xB1, 0xf, 0xf, false);
+  r.i[1] = __builtin_amdgcn_update_dpp(a.i[1], a.i[1], 0xB1, 0xf, 0xf, false);
+  return r.d;
+}
 // sum of lanes 0..15 (lanes 16..63 must hold 0 or are ignored), the same value in every lane
 __device__ __forceinline__ double row0_sum(double v) {
   v += dpp_row_shr(v, 0.0, 1);

@@ -338,7 +338,7 @@ __device__ __forceinline__ void hacc_phase(const LT& L, double* sm, int stage, c
     acc += s0;
     if (paired) {   // wave-uniform: lanes 2i / 2i+1 hold the two halves of one entry, closed in the same slot
       if (__any((int)(w0 >> 31))) {
-        double tot = acc + __shfl_xor(acc, 1, 64);          // even + odd, the same order in both lanes
+        double tot = acc + dpp_swap_pairs(acc);             // own + neighbour (commutative: the same bits in both lanes)
         if ((w0 >> 31) && !(vlane & 1)) {
           int da = (w0 >> 18) & 63u, db = (w0 >> 24) & 63u;
           double v = tot + (da == db ? diag : 0.0);
@@ -357,7 +357,7 @@ __device__ __forceinline__ void hacc_phase(const LT& L, double* sm, int stage, c
     acc += s1;
     if (paired) {
       if (__any((int)(w1 >> 31))) {
-        double tot = acc + __shfl_xor(acc, 1, 64);
+        double tot = acc + dpp_swap_pairs(acc);
         if ((w1 >> 31) && !(vlane & 1)) {
           int da = (w1 >> 18) & 63u, db = (w1 >> 24) & 63u;
           double v = tot + (da == db ? diag : 0.0);

@@ -27,16 +27,6 @@ constexpr int TR_MAX_NL = 8;                     // capacity: limb rows per wave
 constexpr int TR_MAX_NT = 10;                    // capacity: trunk rows
 constexpr int TR_LD = TR_MAX_NL + TR_MAX_NT + 1; // row stride of the LDS transpose scratch
 
-__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
-  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    lo |= (unsigned)__shfl_xor((int)lo, off, 64);
-    hi |= (unsigned)__shfl_xor((int)hi, off, 64);
-  }
-  return ((unsigned long long)hi << 32) | lo;
-}
-
 // Bound sets of the QP, identical in every wavefront (wave-uniform registers, carried from solve to
 // solve for the warm start): bit d of `lower` / `upper` = dof d sits on its lower / upper bound.
 struct TreeState { unsigned long long lower, upper; };
