@@ -52,7 +52,7 @@ __device__ __forceinline__ void wsync() {
 }
 #define WSYNC() wsync<NW>()
 
-enum { CMD_BUILD = 1, CMD_EXIT = 2 };   // CMD_BUILD: assemble the QP, then (tree solver) solve it together
+enum { CMD_BUILD = 1, CMD_EXIT = 2, CMD_JBODY = 3 };   // BUILD: assemble the QP, then solve it together; JBODY: body Jacobians
 
 // Diagnostic phase timer (GMR_IK_PROFILE builds only; never in the shipped kernel): s_memtime
 // stamps accumulated per phase, written to a buffer no other code reads.
@@ -282,6 +282,70 @@ __device__ __forceinline__ void pairs_phase(const LT& L, double* sm, int stage, 
   }
 }
 
+// (b1) 4-wavefront shape, helpers only, right after the FK and concurrently with the main wavefront's residual
+// and Jl^-1 phases: the body-frame Jacobian column of every (task, dof) pair -- it depends on the FK state alone.
+// Stored where the weighted column will go (Jw[p][6] = [jl; ja]).
+template <class LT>
+__device__ __forceinline__ void jbody_phase(const LT& L, double* sm, int stage, const StageTabs& tb, int vlane, int nvl) {
+  const int P = L.P[stage];
+  double* Jw = sm + L.o.Jw;
+  const double* X = sm + L.o.xa;
+  for (int p = vlane; p < P; p += nvl) {
+    const unsigned info = (unsigned short)tb.pair_task[p];       // [3:0] task, [9:4] dof, [15:10] task body
+    const int dof = (info >> 4) & 63u, b = info >> 10;
+    const int c = tb.pair_dof[p];
+    d3 pb = {X[7 * b], X[7 * b + 1], X[7 * b + 2]};
+    d4 qb = {X[7 * b + 3], X[7 * b + 4], X[7 * b + 5], X[7 * b + 6]};
+    d3 lin, ang;
+    if (dof < 3) {
+      lin = d3{dof == 0 ? 1.0 : 0.0, dof == 1 ? 1.0 : 0.0, dof == 2 ? 1.0 : 0.0};
+      ang = d3{0.0, 0.0, 0.0};
+    } else if (dof < 6) {
+      d4 q0 = {X[3], X[4], X[5], X[6]};
+      int a = dof - 3;
+      ang = qrot(q0, d3{a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0});
+      lin = cross(ang, pb - d3{X[0], X[1], X[2]});
+    } else {
+      const double* xa = sm + L.o.xaxis + 3 * c;
+      ang = d3{xa[0], xa[1], xa[2]};
+      lin = cross(ang, pb - d3{X[7 * c], X[7 * c + 1], X[7 * c + 2]});
+    }
+    d3 jl = qrot_inv(qb, lin), ja = qrot_inv(qb, ang);
+    double* o = Jw + 6 * p;
+    o[0] = jl.x; o[1] = jl.y; o[2] = jl.z; o[3] = ja.x; o[4] = ja.y; o[5] = ja.z;
+  }
+}
+
+// (b2) all wavefronts, after Jl^-1: Jw[p] = W_k (-Jl^-1(e_k)) Jb[p] in place, and the column's share of c
+template <class LT>
+__device__ __forceinline__ void pairs_from_jbody(const LT& L, double* sm, int stage, const StageTabs& tb, int vlane, int nvl) {
+  const int P = L.P[stage];
+  const double* wpos = sm + L.o.wpos[stage];
+  const double* wrot = sm + L.o.wrot[stage];
+  double* Jw = sm + L.o.Jw;
+  double* cpart = sm + L.o.cpart;
+  for (int p = vlane; p < P; p += nvl) {
+    const int k = (unsigned short)tb.pair_task[p] & 15u;
+    double* o = Jw + 6 * p;
+    const d3 jl = {o[0], o[1], o[2]}, ja = {o[3], o[4], o[5]};
+    const double* M = sm + L.o.M + 18 * k;
+    const double* we = sm + L.o.we + 6 * k;
+    const double wp = wpos[k], wr = wrot[k];
+    double cp = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      double top = M[3 * r] * jl.x + M[3 * r + 1] * jl.y + M[3 * r + 2] * jl.z + M[9 + 3 * r] * ja.x +
+                   M[9 + 3 * r + 1] * ja.y + M[9 + 3 * r + 2] * ja.z;
+      double bot = M[3 * r] * ja.x + M[3 * r + 1] * ja.y + M[3 * r + 2] * ja.z;
+      top *= wp; bot *= wr;
+      o[r] = top;
+      o[3 + r] = bot;
+      cp += top * we[r] + bot * we[3 + r];
+    }
+    cpart[p] = cp;
+  }
+}
+
 // (c) lane = dof: gather c; bounds of the limited hinges (mink ConfigurationLimit)
 template <class LT>
 __device__ __forceinline__ void cvec_phase(const LT& L, double* sm, int stage, const StageTabs& tb,
@@ -442,8 +506,8 @@ __device__ __forceinline__ void build_qp_main(const LT& L, double* sm, int stage
   } else {
     PROF_BEGIN(pr);
     if (lane == 0) { ctl[0] = CMD_BUILD; ctl[1] = stage; (sm + L.o.scal)[0] = diag; }
-    __syncthreads();                      // B1: helpers see the command, M / we / FK state are final
-    pairs_phase(L, sm, stage, tb, hinge_body, lane, 64 * NW);
+    __syncthreads();                      // B1: helpers see the command; M / we and the body Jacobians are final
+    pairs_from_jbody(L, sm, stage, tb, lane, 64 * NW);
     __syncthreads();                      // B2: all Jacobian columns written
     PROF_END(pr, PH_PAIRS);
     PROF_BEGIN(pr);
@@ -468,11 +532,17 @@ __device__ __forceinline__ void helper_loop(const LT& L, double* sm, const uint3
     const int cmd = ctl[0];
     if (cmd == CMD_EXIT) return;
     const int stage = ctl[1];
-    const double diag = (sm + L.o.scal)[0];
     StageTabs tb = {si + L.o.i_task_body[stage], si + L.o.i_task_human[stage], si + L.o.i_pair_task[stage],
                     si + L.o.i_pair_dof[stage], si + L.o.i_pair_index[stage], sw + L.w_items[stage]};
+    if (cmd == CMD_JBODY) {               // the main wavefront is evaluating the residuals meanwhile
+      PROF_BEGIN(hp);
+      jbody_phase(L, sm, stage, tb, (wave - 1) * 64 + lane, 64 * (NW - 1));
+      PROF_END(hp, PH_PAIRS);
+      continue;
+    }
+    const double diag = (sm + L.o.scal)[0];
     PROF_BEGIN(hp);
-    pairs_phase(L, sm, stage, tb, hinge_body, wave * 64 + lane, 64 * NW);
+    pairs_from_jbody(L, sm, stage, tb, wave * 64 + lane, 64 * NW);
     PROF_END(hp, PH_PAIRS);
     PROF_BEGIN(hp);
     __syncthreads();                      // B2
@@ -799,6 +869,12 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
           h_stage = stage;
           WSYNC();
         }
+        // every residual evaluation is preceded by a kick of the helpers: they turn the FK state into the body
+        // Jacobians of this stage's (task, dof) pairs while this wavefront evaluates residuals and Jl^-1
+        if (NW > 1) {
+          if (lane == 0) { ctl[0] = CMD_JBODY; ctl[1] = stage; }
+          __syncthreads();
+        }
         double curr = errors_wave<NW>(L, sm, tb.task_body, tb.task_human, K, lane, pr);
         int nsol = 0, num_iter = 0;
         for (;;) {
@@ -816,6 +892,10 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
           if (rc != GMR_STATUS_OK) { stat = rc; break; }
           integrate_wave<NW>(L, sm, prm[5], lane, pr);
           fk_wave<NW>(L, sm, hop, depth, body_hinge, lane, pr);
+          if (NW > 1) {
+            if (lane == 0) { ctl[0] = CMD_JBODY; ctl[1] = stage; }
+            __syncthreads();
+          }
           double next = errors_wave<NW>(L, sm, tb.task_body, tb.task_human, K, lane, pr);
           nsol++;
           if (nsol > 1) num_iter++;
