@@ -72,17 +72,20 @@ constexpr IkOffsets ik_offsets(int nvp, int nw) {
   L.xb = L.Jw;                                     // FK runs between solves, when the assembly scratch is dead
   // The transpose scratch of the QP solvers (dense: nvp x (nvp+1); tree: 4 x 18 x 19) is only live inside a
   // solve, when the assembly scratch [e, eaux, we, M, Jw, cpart] is dead: alias it there.
+  // nw == 1: the one-wavefront tree solver (four limbs in the four 16-lane rows) parks 4 x 16 x 19 transposes
+  // and exchanges its Schur parts (4 x 10 x 10 + 4 x 10) in the same dead region.
   {
-    const int need = ik_max(nvp * (nvp + 1), nw == 4 ? 4 * 18 * 19 : 0);
+    const int rows_scr = 4 * 16 * 19;
+    const int need = nw == 4 ? ik_max(nvp * (nvp + 1), 4 * 18 * 19) : ik_max(nvp * (nvp + 1), rows_scr + 440);
     const int have = o - L.e;
     if (have < need) o += need - have;
     L.Kt = L.e;
+    if (nw != 4) { L.tr_spart = L.Kt + rows_scr; L.tr_rpart = L.tr_spart + 400; }
   }
   if (o & 1) o++;
   L.H = o; o += nvp * L.ldh + 2;
   L.c = o; o += nvp; L.x = o; o += nvp; L.lo = o; o += nvp; L.hi = o; o += nvp; L.scal = o; o += 2;
-  L.tr_spart = o; o += nw == 4 ? 4 * 10 * 10 : 0;
-  L.tr_rpart = o; o += nw == 4 ? 4 * 10 : 0;
+  if (nw == 4) { L.tr_spart = o; o += 4 * 10 * 10; L.tr_rpart = o; o += 4 * 10; }
   if (o & 1) o++;                                  // every region starts 16-byte aligned
   L.n_double = o;
   int i = 0;
@@ -328,7 +331,7 @@ inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, co
   IkLayout L{};
   L.nw = nw;
   const IkTree tree = make_ik_tree(m);
-  L.tree_ok = (nw == 4 && tree.ok) ? 1 : 0;
+  L.tree_ok = tree.ok ? 1 : 0;
   L.tree_nt = tree.nt;
   {
     int maxlimb = 0;

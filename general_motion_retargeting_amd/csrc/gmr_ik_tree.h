@@ -37,10 +37,21 @@ struct TreeState { unsigned long long lower, upper; };
 // the only exchanges are the limbs' Schur contributions, the solution x and the violation sets.
 // TR_NL / TR_NT: rows actually eliminated (limbs <= TR_NL dofs, trunk <= TR_NT): the pivots are unrolled, so a
 // robot with 7-dof limbs and a 9-dof trunk (every shipped one) runs the <7, 9> instance: 16 instead of 18 pivots.
-template <int TR_NL, int TR_NT, class LT>
-__device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* sw, const short* si, int wave,
-                                             int lane, TreeState& bs, Prof& pr) {
+//
+// ROWS = true: the same algorithm inside ONE wavefront (the 1-wavefront launch shape).  The four limbs occupy
+// the four 16-lane DPP rows of the wave (TR_NL + TR_NT <= 16: 7 limb rows + 9 trunk rows), "wavefront" becomes
+// "row", v_readlane broadcasts become DPP row broadcasts (one instruction pair serves all four limbs; the
+// result stays in a VGPR), workgroup barriers become LDS fences.  Replaces the dense 36-pivot factorisation
+// of the throughput shape for robots that fit.
+template <int TR_NL, int TR_NT, bool ROWS, class LT>
+__device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* sw, const short* si, int wave_in,
+                                             int lane_in, TreeState& bs, Prof& pr) {
   constexpr int TR_NV = TR_NL + TR_NT;             // local matrix order
+  static_assert(!ROWS || TR_NV <= 16, "a limb's local matrix must fit one 16-lane row");
+  const int wave = ROWS ? (lane_in >> 4) : wave_in;        // which limb this wavefront / row eliminates
+  const int lane = ROWS ? (lane_in & 15) : lane_in;        // row of the local matrix
+#define TR_BCAST(v, k) (ROWS ? row_bcast_d((v), (k)) : readlane_d((v), (k)))
+#define TR_SYNC() do { if (ROWS) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); else __syncthreads(); } while (0)
   const int n = L.nv, ldh = L.o.ldh;
   const double* H = sm + L.o.H;
   const short* limb = si + L.o.i_tree_limb + wave * TR_MAX_NL;     // dof of limb row a, or -1
@@ -50,7 +61,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
   const double* his = sm + L.o.hi;
   double* Spart = sm + L.o.tr_spart;                           // [4][TR_NT][TR_NT]
   double* rpart = sm + L.o.tr_rpart;                           // [4][TR_NT]
-  double* Lscr = sm + L.o.Kt + wave * (TR_MAX_NL + TR_MAX_NT) * TR_LD;           // this wavefront's transpose scratch
+  double* Lscr = sm + L.o.Kt + wave * (ROWS ? 16 : TR_MAX_NL + TR_MAX_NT) * TR_LD;   // this wavefront's / row's transpose scratch
   // violation sets of a round, double-buffered: {to_lower, to_upper, release, flags} x 2
   unsigned long long* vset = reinterpret_cast<unsigned long long*>(sw + L.o.w_tr_mask);
 
@@ -62,7 +73,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
   const double lo = row ? los[dof] : 0.0, hi = row ? his[dof] : 0.0;
   const double ci = row ? (sm + L.o.c)[dof] : 0.0;
   const double* Hrow = H + (row ? dof : 0) * ldh;
-  double cabs = lane < n ? fabs((sm + L.o.c)[lane]) : 0.0;
+  double cabs = lane_in < n ? fabs((sm + L.o.c)[lane_in]) : 0.0;
   const double dual_tol = 1e-13 * (1.0 + rows3_max(cabs));
   const double ptol_lo = 1e-12 * (1.0 + fabs(lo)), ptol_hi = 1e-12 * (1.0 + fabs(hi));
   // column dofs of the local matrix (wave-uniform): limb columns then trunk columns
@@ -111,7 +122,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
     // that the Newton steps overlap the remaining (independent) column updates of this pivot.
     double mydinv = 1.0;
     bool bad = false;
-    double dp = readlane_d(r[0], 0);
+    double dp = TR_BCAST(r[0], 0);
     double dinv = fast_rsqrt(dp);
 #pragma unroll
     for (int p = 0; p < TR_NL; p++) {
@@ -120,14 +131,14 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
       if (lane == p) { mydinv = dinv; r[p] = dp * dinv; } else r[p] = l;
       double dinv_next = 1.0;
       if (p + 1 < TR_NL) {
-        r[p + 1] = fma(-l, readlane_d(l, p + 1), r[p + 1]);
-        dp = readlane_d(r[p + 1], p + 1);
+        r[p + 1] = fma(-l, TR_BCAST(l, p + 1), r[p + 1]);
+        dp = TR_BCAST(r[p + 1], p + 1);
         dinv_next = fast_rsqrt(dp);
       }
-      const double yp = readlane_d(b, p) * dinv;
+      const double yp = TR_BCAST(b, p) * dinv;
       b = lane == p ? yp : fma(-l, yp, b);
 #pragma unroll
-      for (int k = (p + 1 < TR_NL ? p + 2 : p + 1); k < TR_NV; k++) r[k] = fma(-l, readlane_d(l, k), r[k]);
+      for (int k = (p + 1 < TR_NL ? p + 2 : p + 1); k < TR_NV; k++) r[k] = fma(-l, TR_BCAST(l, k), r[k]);
       dinv = dinv_next;
     }
     PROF_END(pr, PH_CHOL);
@@ -144,7 +155,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
     }
     unsigned long long* vcur = vset + 4 * (it & 1);
     if (lane == 0 && bad) atomicOr(&vcur[3], 1ull);
-    __syncthreads();                                                                         // B1
+    TR_SYNC();                                                                               // B1
     // the other slot was last read before this barrier: clear it for the next round
     if (wave == 0 && lane < 4) vset[4 * ((it + 1) & 1) + lane] = 0ull;
     PROF_END(pr, PH_SUBST);
@@ -180,7 +191,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
         bt = is_trunk ? (live ? rhs0 + rp : rhs0) : 0.0;
       }
       double tdinv = 1.0;
-      double dq = readlane_d(s[0], TR_NL);
+      double dq = TR_BCAST(s[0], TR_NL);
       double dinv = fast_rsqrt(dq);
 #pragma unroll
       for (int q = 0; q < TR_NT; q++) {
@@ -189,14 +200,14 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
         if (t == q) { tdinv = dinv; s[q] = dq * dinv; } else s[q] = l;
         double dinv_next = 1.0;
         if (q + 1 < TR_NT) {
-          s[q + 1] = fma(-l, readlane_d(l, TR_NL + q + 1), s[q + 1]);
-          dq = readlane_d(s[q + 1], TR_NL + q + 1);
+          s[q + 1] = fma(-l, TR_BCAST(l, TR_NL + q + 1), s[q + 1]);
+          dq = TR_BCAST(s[q + 1], TR_NL + q + 1);
           dinv_next = fast_rsqrt(dq);
         }
-        const double yq = readlane_d(bt, TR_NL + q) * dinv;
+        const double yq = TR_BCAST(bt, TR_NL + q) * dinv;
         bt = t == q ? yq : fma(-l, yq, bt);
 #pragma unroll
-        for (int k = q + 2; k < TR_NT; k++) s[k] = fma(-l, readlane_d(l, TR_NL + k), s[k]);
+        for (int k = q + 2; k < TR_NT; k++) s[k] = fma(-l, TR_BCAST(l, TR_NL + k), s[k]);
         dinv = dinv_next;
       }
       // back substitution: L^T through this wavefront's scratch (columns 8..17 of rows 8..17 are free)
@@ -211,7 +222,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
       for (int q = 0; q < TR_NT; q++) lt[q] = is_trunk ? Tscr[(TR_NL + q) * TR_LD + t] : 0.0;
 #pragma unroll
       for (int q = TR_NT - 1; q >= 0; q--) {
-        const double xq = readlane_d(bt * tdinv, TR_NL + q);
+        const double xq = TR_BCAST(bt * tdinv, TR_NL + q);
         bt = t == q ? xq : (is_trunk && t < q ? fma(-lt[q], xq, bt) : bt);
       }
     }
@@ -226,12 +237,12 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
       double bb = b;                                                                   // y_l (limb lanes)
 #pragma unroll
       for (int u = 0; u < TR_NT; u++) {
-        const double xt = readlane_d(bt, TR_NL + u);
+        const double xt = TR_BCAST(bt, TR_NL + u);
         if (is_limb) bb = fma(-Lscr[(TR_NL + u) * TR_LD + a], xt, bb);                 // Y_l[u][a]
       }
 #pragma unroll
       for (int p = TR_NL - 1; p >= 0; p--) {
-        const double xp = readlane_d(bb * mydinv, p);
+        const double xp = TR_BCAST(bb * mydinv, p);
         bb = lane == p ? xp : (lane < p ? fma(-lt[p], xp, bb) : bb);
       }
       if (is_limb) x = bb;
@@ -239,7 +250,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
     // ---- (6) violated bounds (free set) / multipliers (fixed set): g = H x + c ---------------------
     if (fixedm != 0ull) {                                     // multipliers need the whole x
       if (own) xs[dof] = x;
-      __syncthreads();                                                                       // B2
+      TR_SYNC();                                                                             // B2
     }
     PROF_END(pr, PH_MULT);
     PROF_BEGIN(pr);
@@ -261,14 +272,14 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
     // each violating owner lane sets its dof's bit in the round's set (LDS atomic OR: order-independent)
     if (newst != 0) atomicOr(&vcur[newst - 1], 1ull << dof);
     if (lane == 0 && tbad) atomicOr(&vcur[3], 1ull);
-    __syncthreads();                                                                         // B3
+    TR_SYNC();                                                                               // B3
     PROF_END(pr, PH_IO);
     const unsigned long long to_lo = vcur[0], to_up = vcur[1], rel = vcur[2];
     if (vcur[3]) return GMR_STATUS_QP_FAILED;
     const unsigned long long all = to_lo | to_up | rel;
     if (all == 0ull) {
       if (own) xs[dof] = fmin(fmax(x, lo), hi);
-      __syncthreads();
+      TR_SYNC();
       return GMR_STATUS_OK;
     }
     const int total = __popcll(all);
@@ -280,6 +291,8 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
     bs.upper = (bs.upper & ~(rel & sel)) | (to_up & sel);
   }
   return GMR_STATUS_QP_MAXITER;
+#undef TR_BCAST
+#undef TR_SYNC
 }
 
 }  // namespace gmr

@@ -111,9 +111,10 @@ int main(int argc, char** argv) {
     CHECK((L.o.ldh & 1) == 1 && L.o.ldh > nv, "odd H row stride");
     std::vector<char> img = gmr::make_ik_image(m, ts, sch, L);
     CHECK((int)img.size() >= L.smem_bytes && img.size() % 16 == 0, "image size");
-    CHECK(L.tree_ok == ((nw == 4 && tr.ok) ? 1 : 0), "tree flag");
+    CHECK(L.tree_ok == (tr.ok ? 1 : 0), "tree flag");
     {   // the QP transpose scratch may alias the assembly scratch, never H / c / x / lo / hi
-      const int need = std::max(L.nvp * (L.nvp + 1), nw == 4 ? 4 * 18 * 19 : 0);
+      const int need = nw == 4 ? std::max(L.nvp * (L.nvp + 1), 4 * 18 * 19) : std::max(L.nvp * (L.nvp + 1), 4 * 16 * 19 + 440);
+      CHECK(L.o.tr_spart >= L.o.Kt && L.o.tr_rpart + 40 <= (nw == 4 ? L.o.n_double : L.o.H), "Schur exchange area");
       CHECK(L.o.Kt >= L.o.e && L.o.Kt + need <= L.o.H, "Kt [%d,%d) overlaps H at %d", L.o.Kt, L.o.Kt + need, L.o.H);
       CHECK(L.o.H + nv * L.o.ldh <= L.o.c, "H overlaps c");
     }
