@@ -28,8 +28,9 @@ extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree*, int, int, int, con
 extern "C" int gmr_fk_blocks(int nbody, int B);
 
 // up to this many streams a launch uses the 4-wave (main + 3 helpers) shape; measured crossover on MI355X
-// (tools/shape_sweep.py, G1): S=384 1.05M vs 1.02M frames/s, S=512 1.02M vs 1.32M (NW=4 vs NW=1)
-#define GMR_HELPER_MAX_STREAMS 400
+// (tools/shape_sweep.py, G1): S=256 1.04M vs 0.93M frames/s, S=384 1.24M vs 1.40M (NW=4 vs NW=1): the switch
+// sits just above one workgroup per CU (256 CUs)
+#define GMR_HELPER_MAX_STREAMS 300
 
 namespace {
 thread_local char g_err[512] = "";

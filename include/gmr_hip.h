@@ -72,7 +72,7 @@ int gmr_solver_create(const gmr_model_t* model, const gmr_taskset_t* taskset, gm
 int gmr_solver_destroy(gmr_solver_t* solver);
 int gmr_solver_dims(const gmr_solver_t* solver, int* nq, int* nv, int* nhuman);
 /* Launch shape of the IK kernel: 1 = one wavefront per stream (most streams resident), 4 = one main
- * wavefront + 3 helper wavefronts per stream (shortest per-frame latency), 0 = automatic (4 up to 400
+ * wavefront + 3 helper wavefronts per stream (shortest per-frame latency), 0 = automatic (4 up to 300
  * streams per launch, 1 above).  The 4-wavefront shape needs a robot whose dofs split into <= 4 limbs of <= 8
  * and a trunk of <= 10 (all shipped robots do); other robots always run the 1-wavefront shape.  Results agree
  * to rounding between the shapes; no reference analogue. */
