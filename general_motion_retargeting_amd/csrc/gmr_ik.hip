@@ -1,13 +1,13 @@
 // gmr_ik.hip -- the retargeting hot path (rows H2-H7 of SURVEY.md section 8a) as ONE gfx950 kernel.
 //
-// One 64-lane wavefront per motion stream (clip / robot instance).  Frames of a stream are
-// sequentially dependent (the configuration is warm-started from the previous frame, reference
-// motion_retarget.py:75,139-185), so the time loop runs on the device and the parallel width of a
-// launch is the number of streams.  Everything a stream touches between two frames lives in LDS or
-// in registers:
+// One workgroup per motion stream (clip / robot instance): one 64-lane wavefront (NW = 1, many streams) or a main
+// wavefront plus three helpers (NW = 4, few streams).  Frames of a stream are sequentially dependent (the
+// configuration is warm-started from the previous frame, reference motion_retarget.py:75,139-185), so the time
+// loop runs on the device and the parallel width of a launch is the number of streams.  Everything a stream
+// touches between two frames lives in LDS (at compile-time offsets, gmr_ik_layout.h) or in registers:
 //
-//   LDS constants  joint-local transforms (body pos/quat, hinge axes), limits, task tables,
-//                  the static H-assembly schedule
+//   LDS constants  joint-local transforms (body pos/quat, hinge axes), limits, task tables, solve parameters
+//                  (NW = 4: also the static H-assembly schedule; NW = 1 streams it from global memory)
 //   LDS state      q, FK ping-pong (pos, quat per body), world hinge axes, targets, residuals e_k,
 //                  -Jl^-1(e_k), weighted per-(task,dof) Jacobian columns, H, c, bounds
 //   registers      the working copy of H during the factorisation: lane i holds row i
@@ -19,18 +19,22 @@
 // Lane mapping per phase
 //   FK          lane = body; log2(depth) rounds of pointer jumping over the kinematic tree
 //               (transform composition is associative), ping-pong buffers in LDS
-//   residuals   lane = task: e_k = log(T_wb^-1 T_wt); wave butterfly for |e|
+//   residuals   lane = task: e_k = log(T_wb^-1 T_wt); DPP row reduction for |e|
 //   Jl^-1       lane = task
 //   Jacobian    lane = (task, ancestor dof) pair: weighted column W_k (-Jl^-1) J_body[:, d]
 //   H           lane = owner of a set of H entries (static LPT schedule, gmr_ik_layout.h): the
 //               Jacobian of a task is non-zero only on its root->frame path, so H is assembled
 //               block-sparse (6k instead of 103k multiply-adds for G1), one store per entry
-//   QP          lane = row of H.  Dense Cholesky with the row in registers, fully unrolled:
-//               pivot column broadcast through v_readlane (SGPR operands), no LDS in the
-//               factorisation; L^T for the back substitution through one LDS transpose.
-//               Box constraints: block principal pivoting (all violated bounds / multipliers are
-//               exchanged at once, Murty's single exchange as the finite-termination fallback),
-//               warm-started from the previous solve's active set.
+//   QP          tree-structured (gmr_ik_tree.h): the dofs split into <= 4 limbs and a trunk, H is block-arrowhead.
+//               NW = 4: one limb per wavefront; NW = 1: one limb per 16-lane DPP row of the single wavefront.
+//               Robots that do not decompose (NW = 1 only): lane = row of H, dense Cholesky with the row in
+//               registers, pivot column broadcast through v_readlane, L^T through one LDS transpose.
+//               Box constraints: block principal pivoting (all violated bounds / multipliers are exchanged at
+//               once, Murty's single exchange as the finite-termination fallback), warm-started from the
+//               previous solve's active set.
+//   NW = 4      the helpers (i) turn each new FK state into the body Jacobians while the main wavefront
+//               evaluates residuals and Jl^-1, (ii) share the weighted Jacobian columns, (iii) assemble H while
+//               the main wavefront gathers c and the bounds, (iv) eliminate one limb each in the QP.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
