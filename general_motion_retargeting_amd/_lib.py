@@ -12,7 +12,7 @@ import numpy as np
 from .ik_config import MODEL_DTYPE, TASKSET_DTYPE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgmrhip.so")
+LIB_PATH = os.environ.get("GMR_HIP_LIBRARY") or os.path.join(_HERE, "libgmrhip.so")   # override: A/B builds of the library
 _lib = None
 
 FLAG_OFFSET_TO_GROUND = 1

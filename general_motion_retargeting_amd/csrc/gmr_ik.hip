@@ -558,8 +558,8 @@ __device__ __forceinline__ void helper_loop(const LT& L, double* sm, const uint3
     __syncthreads();                      // B3
     PROF_END(hp, PH_JLOG);                // wait at B3
     // NW > 1 is only launched for robots that decompose
-    if (L.tree_small) (void)solve_qp_tree<7, 9, false>(L, sm, const_cast<uint32_t*>(sw), si, wave, lane, bs, hp);
-    else (void)solve_qp_tree<8, 10, false>(L, sm, const_cast<uint32_t*>(sw), si, wave, lane, bs, hp);
+    if (L.tree_small) (void)solve_qp_tree<7, 9, false, true>(L, sm, const_cast<uint32_t*>(sw), si, wave, lane, bs, hp);
+    else (void)solve_qp_tree<8, 10, false, false>(L, sm, const_cast<uint32_t*>(sw), si, wave, lane, bs, hp);
   }
 }
 
@@ -888,11 +888,11 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
           if (NW > 1) {   // the 4-wavefront shape is only launched for robots that decompose (gmr_abi.hip)
             PROF_COUNT(pr, PH_NFACT);
             // helpers joined after barrier B3
-            rc = L.tree_small ? solve_qp_tree<7, 9, false>(L, sm, sw, si, 0, lane, tree_state, pr)
-                              : solve_qp_tree<8, 10, false>(L, sm, sw, si, 0, lane, tree_state, pr);
+            rc = L.tree_small ? solve_qp_tree<7, 9, false, true>(L, sm, sw, si, 0, lane, tree_state, pr)
+                              : solve_qp_tree<8, 10, false, false>(L, sm, sw, si, 0, lane, tree_state, pr);
           } else if (L.tree_small) {   // one wavefront, the four limbs in its four 16-lane rows
             PROF_COUNT(pr, PH_NFACT);
-            rc = solve_qp_tree<7, 9, true>(L, sm, sw, si, 0, lane, tree_state, pr);
+            rc = solve_qp_tree<7, 9, true, true>(L, sm, sw, si, 0, lane, tree_state, pr);
           } else {
             rc = solve_qp_regs<NVP, NW>(L, sm, lane, qp_state, pr);
           }

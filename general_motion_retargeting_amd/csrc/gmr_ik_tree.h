@@ -43,14 +43,15 @@ struct TreeState { unsigned long long lower, upper; };
 // "row", v_readlane broadcasts become DPP row broadcasts (one instruction pair serves all four limbs; the
 // result stays in a VGPR), workgroup barriers become LDS fences.  Replaces the dense 36-pivot factorisation
 // of the throughput shape for robots that fit.
-template <int TR_NL, int TR_NT, bool ROWS, class LT>
+template <int TR_NL, int TR_NT, bool ROWS, bool DPPB, class LT>
 __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* sw, const short* si, int wave_in,
                                              int lane_in, TreeState& bs, Prof& pr) {
   constexpr int TR_NV = TR_NL + TR_NT;             // local matrix order
   static_assert(!ROWS || TR_NV <= 16, "a limb's local matrix must fit one 16-lane row");
   const int wave = ROWS ? (lane_in >> 4) : wave_in;        // which limb this wavefront / row eliminates
   const int lane = ROWS ? (lane_in & 15) : lane_in;        // row of the local matrix
-#define TR_BCAST(v, k) (ROWS ? row_bcast_d((v), (k)) : readlane_d((v), (k)))
+  static_assert(!DPPB || TR_NV <= 16, "DPP row broadcasts need the local matrix in one 16-lane row");
+#define TR_BCAST(v, k) ((ROWS || DPPB) ? row_bcast_d((v), (k)) : readlane_d((v), (k)))
 #define TR_SYNC() do { if (ROWS) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); else __syncthreads(); } while (0)
   const int n = L.nv, ldh = L.o.ldh;
   const double* H = sm + L.o.H;
