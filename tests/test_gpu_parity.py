@@ -521,3 +521,28 @@ def test_robot_promoted_to_larger_size_class(hip, oracle, tmp_path):
         assert (st_h == 0).all() and np.array_equal(ns_h, ns_o), waves
         joint, pos, rot = _compare(q_h, q_o)
         assert joint <= 1e-8 and pos <= 1e-8 and rot <= 1e-8, (waves, joint, pos, rot)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src,robot", [("smplx", "unitree_g1"), ("bvh", "booster_t1")])
+def test_many_joints_on_their_limits(hip, oracle, src, robot):
+    """Targets far from reachable (0.3 m / 40 deg noise, skeleton stretched) put many joints on their limits at
+    once: block principal pivoting, multiplier checks and the warm start of the bound sets are exercised in both
+    QP code paths (tree solver over four wavefronts; tree solver in the DPP rows of one wavefront)."""
+    from general_motion_retargeting_amd import synth
+    su = get_setup(src, robot, 1.7)
+    human, q0 = synth.make_streams(su.model, su.tt, 24, 12, seed=911, pos_noise=0.30, rot_noise_deg=40.0)
+    root = human[:, :, :1, :3].copy()
+    human[..., :3] = root + (human[..., :3] - root) * 1.3
+    q_o, ns_o, st_o = oracle.retarget_streams(su.mb, su.ts, q0, human)
+    assert (st_o == 0).all()
+    th = q_o[..., 7:]
+    on_limit = ((th <= su.model.range_lo + 1e-9) | (th >= su.model.range_hi - 1e-9)).mean()
+    assert on_limit > 0.03, on_limit                                     # the case really is bound-heavy
+    sol = hip.Solver(su.mb, su.ts)
+    for waves in (4, 1):
+        sol.set_waves(waves)
+        q_h, ns_h, st_h = sol.retarget_streams(q0, human)
+        assert (st_h == 0).all() and np.array_equal(ns_h, ns_o), waves
+        joint, pos, rot = _compare(q_h, q_o)
+        assert joint <= 1e-9 and pos <= 1e-9 and rot <= 1e-9, (waves, joint, pos, rot)
