@@ -123,8 +123,9 @@ __device__ __forceinline__ void fk_wave(const LT& L, double* sm, const short* ho
       int h = body_hinge[lane];
       if (h >= 0) {
         const double* ax = sm + L.o.axis + 3 * lane;
-        double th = q[7 + h];
-        if (th != 0.0) quat = qmul(quat, axis_angle(d3{ax[0], ax[1], ax[2]}, th));
+        const double* sc = sm + L.o.hsc + 2 * h;       // sin, cos of q[7 + h] / 2 (hinge_sincos / integrate_wave)
+        const double s = sc[0], c = sc[1];
+        quat = qmul(quat, d4{c, ax[0] * s, ax[1] * s, ax[2] * s});
       }
     }
   }
@@ -710,6 +711,17 @@ __device__ __forceinline__ int solve_qp_regs(const LT& L, double* sm, int lane, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// (sin, cos) of every hinge's half angle for a configuration that did not come out of integrate_wave (q0)
+template <class LT>
+__device__ __forceinline__ void hinge_sincos(const LT& L, double* sm, int lane) {
+  if (lane >= 6 && lane < L.nv) {
+    double s, c;
+    sincos(0.5 * (sm + L.o.q)[7 + lane - 6], &s, &c);
+    double* sc = sm + L.o.hsc + 2 * (lane - 6);
+    sc[0] = s; sc[1] = c;
+  }
+}
+
 // mj_integratePos with v = dq/dt (App. A.7): lane 0 the free joint, lane 6+h hinge h
 // ---------------------------------------------------------------------------------------------
 template <int NW, class LT>
@@ -717,19 +729,31 @@ __device__ __forceinline__ void integrate_wave(const LT& L, double* sm, double d
   PROF_BEGIN(pr);
   double* q = sm + L.o.q;
   const double* dq = sm + L.o.x;
-  if (lane == 0) {
+  // ONE sincos serves both uses of this phase: lane 0 needs the half angle of the base rotation increment,
+  // the hinge lanes the half angle of their new joint value (consumed by the next FK, which then needs none)
+  const bool base = lane == 0, hinge = lane >= 6 && lane < L.nv;
+  double half = 0.0, inv = 0.0;
+  bool rotate = false;
+  if (base) {
     // v = dq / dt followed by dt * v (solve_ik / mj_integratePos) is dq to 1 ulp: integrate dq directly
     q[0] += dq[0]; q[1] += dq[1]; q[2] += dq[2];
-    double n2 = dq[3] * dq[3] + dq[4] * dq[4] + dq[5] * dq[5];
+    const double n2 = dq[3] * dq[3] + dq[4] * dq[4] + dq[5] * dq[5];
+    rotate = n2 >= 1e-30 * dt * dt;
+    if (rotate) { inv = rsqrt(n2); half = 0.5 * (n2 * inv); }
+  } else if (hinge) {
+    const double th = q[7 + lane - 6] + dq[lane];
+    q[7 + lane - 6] = th;
+    half = 0.5 * th;
+  }
+  double s, c;
+  sincos(half, &s, &c);
+  if (base) {
     d4 quat = qnormalize(d4{q[3], q[4], q[5], q[6]});
-    if (n2 >= 1e-30 * dt * dt) {
-      double inv = rsqrt(n2);
-      double ang = n2 * inv;
-      quat = qmul(quat, axis_angle(d3{dq[3] * inv, dq[4] * inv, dq[5] * inv}, ang));
-    }
+    if (rotate) quat = qmul(quat, d4{c, dq[3] * inv * s, dq[4] * inv * s, dq[5] * inv * s});
     q[3] = quat.w; q[4] = quat.x; q[5] = quat.y; q[6] = quat.z;
-  } else if (lane >= 6 && lane < L.nv) {
-    q[7 + lane - 6] += dq[lane];
+  } else if (hinge) {
+    double* sc = sm + L.o.hsc + 2 * (lane - 6);
+    sc[0] = s; sc[1] = c;
   }
   WSYNC();
   PROF_END(pr, PH_INTEG);
@@ -832,6 +856,8 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
   const int use0 = P.use0, use1 = P.use1;
 
   for (int i = lane; i < nq; i += 64) (sm + L.o.q)[i] = q0[(size_t)s * nq + i];
+  WSYNC();
+  hinge_sincos(L, sm, lane);
   WSYNC();
   fk_wave<NW>(L, sm, hop, depth, body_hinge, lane, pr);
 

@@ -35,6 +35,7 @@ struct IkOffsets {
   int wpos[2], wrot[2];
   int q, xa, xb, xaxis, raw, tgt, e, eaux, we, M, Jw, cpart, H, Kt, c, x, lo, hi, scal, tr_spart, tr_rpart;
   int params;                    // damping, lm_damping, tol, limit_gain, ground_offset, dt (read where used: not in SGPRs)
+  int hsc;                       // (sin, cos) of every hinge's half angle, written where q changes, read by the FK
   int n_double;
   // offsets in shorts (after the doubles)
   int i_hop, i_depth, i_body_hinge, i_hinge_body, i_limited, i_is_foot, i_tree_limb, i_tree_trunk;
@@ -60,6 +61,7 @@ constexpr IkOffsets ik_offsets(int nvp, int nw) {
   L.scale = o; o += cp.nhum; L.pos_off = o; o += 3 * cp.nhum; L.quat_off = o; o += 4 * cp.nhum;
   for (int s = 0; s < 2; s++) { L.wpos[s] = o; o += cp.k; L.wrot[s] = o; o += cp.k; }
   L.q = o; o += 7 + cp.nh + 1;
+  L.hsc = o; o += 2 * cp.nh;
   L.xa = o; o += 7 * cp.nb + 1;                    // FK result; the second buffer of the FK rounds aliases Jw
   L.xaxis = o; o += 3 * cp.nb;
   L.tgt = o; o += 7 * cp.nhum + 1;
