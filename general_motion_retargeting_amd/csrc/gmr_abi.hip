@@ -22,7 +22,7 @@ static_assert(offsetof(gmr_taskset_t, damping) % 8 == 0, "double block of gmr_ta
 extern "C" hipError_t gmr_launch_ik_streams(const uint4*, const gmr::IkLayout*, const gmr::IkParams*, int, int,
                                             const double*, const double*, const int32_t*, int, double*, int32_t*,
                                             int32_t*, hipStream_t, unsigned long long*);
-extern "C" hipError_t gmr_ik_set_max_smem(int nvp, int nw, int bytes);
+extern "C" hipError_t gmr_ik_set_max_smem(int nvp, int nw, int tree_small, int bytes);
 extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree*, int, int, int, const float*, const float*, const float*,
                                           float*, float*, float*, float*, hipStream_t);
 extern "C" int gmr_fk_blocks(int nbody, int B);
@@ -216,7 +216,7 @@ int gmr_solver_create(const gmr_model_t* model, const gmr_taskset_t* taskset, gm
     uint4** dst = v == 0 ? &s->d_image : &s->d_image4;
     if ((e = hipMalloc((void**)dst, img.size())) != hipSuccess) break;
     if ((e = hipMemcpy(*dst, img.data(), img.size(), hipMemcpyHostToDevice)) != hipSuccess) break;
-    e = gmr_ik_set_max_smem(lay.nvp, nw, lay.smem_bytes);
+    e = gmr_ik_set_max_smem(lay.nvp, nw, lay.tree_small, lay.smem_bytes);
   }
   if (e != hipSuccess) {
     if (s->d_image) (void)hipFree(s->d_image);

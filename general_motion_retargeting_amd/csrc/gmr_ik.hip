@@ -56,6 +56,10 @@ __device__ __forceinline__ void wsync() {
 }
 #define WSYNC() wsync<NW>()
 
+#ifndef GMR_IK_MIN_WAVES
+#define GMR_IK_MIN_WAVES 1
+#endif
+enum { QP_DENSE = 0, QP_TREE_SMALL = 1, QP_TREE = 2 };   // solver carried by a kernel instance
 enum { CMD_BUILD = 1, CMD_EXIT = 2, CMD_JBODY = 3 };   // BUILD: assemble the QP, then solve it together; JBODY: body Jacobians
 
 // Diagnostic phase timer (GMR_IK_PROFILE builds only; never in the shipped kernel): s_memtime
@@ -525,7 +529,7 @@ __device__ __forceinline__ void build_qp_main(const LT& L, double* sm, int stage
 }
 
 // helper waves (NW > 1): serve assembly requests until the main wave says EXIT
-template <int NW, class LT>
+template <int NW, int QP, class LT>
 __device__ __forceinline__ void helper_loop(const LT& L, double* sm, const uint32_t* sw, const short* si,
                                             const short* hinge_body, const int* ctl, int wave, int lane,
                                             Prof& hp) {
@@ -559,7 +563,7 @@ __device__ __forceinline__ void helper_loop(const LT& L, double* sm, const uint3
     __syncthreads();                      // B3
     PROF_END(hp, PH_JLOG);                // wait at B3
     // NW > 1 is only launched for robots that decompose
-    if (L.tree_small) (void)solve_qp_tree<7, 9, false, true>(L, sm, const_cast<uint32_t*>(sw), si, wave, lane, bs, hp);
+    if (QP == QP_TREE_SMALL) (void)solve_qp_tree<7, 9, false, true>(L, sm, const_cast<uint32_t*>(sw), si, wave, lane, bs, hp);
     else (void)solve_qp_tree<8, 10, false, false>(L, sm, const_cast<uint32_t*>(sw), si, wave, lane, bs, hp);
   }
 }
@@ -805,8 +809,10 @@ __device__ __forceinline__ void preprocess_wave(const LT& L, double* sm, const s
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
-template <int NVP, int NW>
-__global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __restrict__ image, IkLay<NVP, NW> L, IkParams P,
+// QP: which box-QP solver the instance carries (one per instance: the dense solver's 2 x NVP row registers would
+// otherwise set the register allocation of robots that never run it)
+template <int NVP, int NW, int QP>
+__global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(const uint4* __restrict__ image, IkLay<NVP, NW> L, IkParams P,
                                                              int S, int T, const double* __restrict__ q0,
                                                              const double* __restrict__ human,
                                                              const int32_t* __restrict__ len, int flags,
@@ -844,7 +850,7 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
   }
   __syncthreads();
   if (NW > 1 && wave > 0) {
-    helper_loop<NW>(L, sm, sw, si, hinge_body, ctl, wave, lane, pr);
+    helper_loop<NW, QP>(L, sm, sw, si, hinge_body, ctl, wave, lane, pr);
 #ifdef GMR_IK_PROFILE
     if (wave == 1 && lane == 0 && prof_out)      // second row of stamps: helper wavefront 1
       for (int i = 0; i < PH_COUNT; i++) prof_out[((size_t)S + s) * PH_COUNT + i] = pr.acc[i];
@@ -914,9 +920,9 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
           if (NW > 1) {   // the 4-wavefront shape is only launched for robots that decompose (gmr_abi.hip)
             PROF_COUNT(pr, PH_NFACT);
             // helpers joined after barrier B3
-            rc = L.tree_small ? solve_qp_tree<7, 9, false, true>(L, sm, sw, si, 0, lane, tree_state, pr)
-                              : solve_qp_tree<8, 10, false, false>(L, sm, sw, si, 0, lane, tree_state, pr);
-          } else if (L.tree_small) {   // one wavefront, the four limbs in its four 16-lane rows
+            rc = QP == QP_TREE_SMALL ? solve_qp_tree<7, 9, false, true>(L, sm, sw, si, 0, lane, tree_state, pr)
+                                     : solve_qp_tree<8, 10, false, false>(L, sm, sw, si, 0, lane, tree_state, pr);
+          } else if (QP == QP_TREE_SMALL) {   // one wavefront, the four limbs in its four 16-lane rows
             PROF_COUNT(pr, PH_NFACT);
             rc = solve_qp_tree<7, 9, true, true>(L, sm, sw, si, 0, lane, tree_state, pr);
           } else {
@@ -963,23 +969,26 @@ __global__ __launch_bounds__(64 * NW) void ik_streams_kernel(const uint4* __rest
 
 // host-side launchers used by gmr_abi.hip.  NW = 1: one wave per stream (throughput shape, many
 // streams); NW = 4: one main wave + 3 helpers per stream (latency shape: fewer streams than the chip
-// has SIMDs, the helpers share the two wide assembly phases).
-template <int NVP, int NW>
+// has SIMDs, the helpers share the two wide assembly phases).  The solver of an instance follows from the
+// robot's decomposition: NW = 1 runs the tree solver in DPP rows (<7, 9> fits a row) or the dense one,
+// NW = 4 (only launched for robots that decompose) the <7, 9> or the <8, 10> tree instance.
+template <int NVP, int NW, int QP>
 static hipError_t launch_nvp(const uint4* d_image, const gmr::IkLayout* L, const gmr::IkParams* P, int S, int T,
                              const double* d_q0, const double* d_human,
                              const int32_t* d_len, int flags, double* d_q_out, int32_t* d_nsolve, int32_t* d_status,
                              hipStream_t stream, unsigned long long* d_prof) {
-  hipLaunchKernelGGL((gmr::ik_streams_kernel<NVP, NW>), dim3(S), dim3(64 * NW), L->smem_bytes, stream, d_image,
+  hipLaunchKernelGGL((gmr::ik_streams_kernel<NVP, NW, QP>), dim3(S), dim3(64 * NW), L->smem_bytes, stream, d_image,
                      gmr::IkLay<NVP, NW>(static_cast<const gmr::IkDims&>(*L)), *P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, d_prof);
   return hipGetLastError();
 }
 
-#define GMR_DISPATCH(NVP_)                                                                                       \
-  case NVP_:                                                                                                     \
-    return L->nw == 1 ? launch_nvp<NVP_, 1>(d_image, L, P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, \
-                                            d_status, stream, d_prof)                                            \
-                      : launch_nvp<NVP_, 4>(d_image, L, P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, \
-                                            d_status, stream, d_prof);
+#define GMR_ARGS d_image, L, P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream, d_prof
+#define GMR_DISPATCH(NVP_)                                                                             \
+  case NVP_:                                                                                           \
+    if (L->nw == 1) return L->tree_small ? launch_nvp<NVP_, 1, gmr::QP_TREE_SMALL>(GMR_ARGS)           \
+                                         : launch_nvp<NVP_, 1, gmr::QP_DENSE>(GMR_ARGS);               \
+    return L->tree_small ? launch_nvp<NVP_, 4, gmr::QP_TREE_SMALL>(GMR_ARGS)                           \
+                         : launch_nvp<NVP_, 4, gmr::QP_TREE>(GMR_ARGS);
 
 extern "C" hipError_t gmr_launch_ik_streams(const uint4* d_image, const gmr::IkLayout* L, const gmr::IkParams* P,
                                             int S, int T, const double* d_q0, const double* d_human,
@@ -995,19 +1004,22 @@ extern "C" hipError_t gmr_launch_ik_streams(const uint4* d_image, const gmr::IkL
   }
 }
 
-#define GMR_ATTR(NVP_)                                                                                  \
-  case NVP_:                                                                                            \
-    f = nw == 1 ? reinterpret_cast<const void*>(gmr::ik_streams_kernel<NVP_, 1>)                        \
-                : reinterpret_cast<const void*>(gmr::ik_streams_kernel<NVP_, 4>);                       \
-    break;
+template <int NVP>
+static const void* kernel_of(int nw, int tree_small) {
+  if (nw == 1) return tree_small ? reinterpret_cast<const void*>(gmr::ik_streams_kernel<NVP, 1, gmr::QP_TREE_SMALL>)
+                                 : reinterpret_cast<const void*>(gmr::ik_streams_kernel<NVP, 1, gmr::QP_DENSE>);
+  return tree_small ? reinterpret_cast<const void*>(gmr::ik_streams_kernel<NVP, 4, gmr::QP_TREE_SMALL>)
+                    : reinterpret_cast<const void*>(gmr::ik_streams_kernel<NVP, 4, gmr::QP_TREE>);
+}
 
-extern "C" hipError_t gmr_ik_set_max_smem(int nvp, int nw, int bytes) {
+// opt the instance that (nvp, nw, tree_small) selects into `bytes` of dynamic LDS on the CURRENT device
+extern "C" hipError_t gmr_ik_set_max_smem(int nvp, int nw, int tree_small, int bytes) {
   const void* f = nullptr;
   switch (nvp) {
-    GMR_ATTR(28)
-    GMR_ATTR(32)
-    GMR_ATTR(36)
-    GMR_ATTR(48)
+    case 28: f = kernel_of<28>(nw, tree_small); break;
+    case 32: f = kernel_of<32>(nw, tree_small); break;
+    case 36: f = kernel_of<36>(nw, tree_small); break;
+    case 48: f = kernel_of<48>(nw, tree_small); break;
     default: return hipErrorInvalidValue;
   }
   return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

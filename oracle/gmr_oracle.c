@@ -569,6 +569,154 @@ void orc_retarget_streams(const gmr_model_t* m, const gmr_taskset_t* ts, int S, 
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Parity-risk audit (tools/parity_risk.py): how far could the genuine stack (DAQP behind        */
+/* qpsolvers, primal tolerance ~1e-6) be from this restatement, which solves every QP exactly?   */
+/* ------------------------------------------------------------------------------------------ */
+/* DAQP is a dual active-set method: its iterates solve the equality-constrained problem of a working set
+ * exactly and it stops as soon as no constraint is violated by more than its primal tolerance.  The emulation
+ * below has that termination rule: a bound violated by <= ptol is never added to the working set and the
+ * returned x is NOT clipped (qpsolvers hands DAQP's x to mink unchanged).  ptol = 0 gives the exact minimiser.
+ * Returns the number of factorisations or <0. */
+int orc_solve_box_qp_relaxed(int n, const double* H, const double* c, const double* lo, const double* hi,
+                             double ptol, double* x) {
+  int st[NV];
+  double K[NV * NV], xe[NV];
+  double cmax = 0;
+  for (int i = 0; i < n; i++) { st[i] = 0; if (fabs(c[i]) > cmax) cmax = fabs(c[i]); }
+  const double dual_tol = 1e-12 * (1.0 + cmax);
+  for (int it = 0; it < 16 * n + 16; it++) {
+    for (int i = 0; i < n; i++) {
+      if (st[i]) {
+        for (int j = 0; j < n; j++) K[i * n + j] = K[j * n + i] = 0.0;
+        K[i * n + i] = 1.0;
+        xe[i] = st[i] < 0 ? lo[i] : hi[i];
+        continue;
+      }
+      double r = -c[i];
+      for (int j = 0; j < n; j++) {
+        if (st[j]) r -= H[i * n + j] * (st[j] < 0 ? lo[j] : hi[j]);
+        else K[i * n + j] = H[i * n + j];
+      }
+      xe[i] = r;
+    }
+    for (int i = 0; i < n; i++) if (st[i]) for (int j = 0; j < n; j++) if (j != i) K[j * n + i] = 0.0;
+    if (chol_solve(n, K, xe)) return -1;
+    /* most violated bound among the free variables (beyond the primal tolerance) joins the working set */
+    double worst = ptol;
+    int add = -1, side = 0;
+    for (int i = 0; i < n; i++) {
+      if (st[i]) continue;
+      if (lo[i] - xe[i] > worst) { worst = lo[i] - xe[i]; add = i; side = -1; }
+      if (xe[i] - hi[i] > worst) { worst = xe[i] - hi[i]; add = i; side = 1; }
+    }
+    if (add >= 0) { st[add] = side; continue; }
+    /* multipliers of the working set */
+    double wd = dual_tol;
+    int rel = -1;
+    for (int i = 0; i < n; i++) {
+      if (!st[i]) continue;
+      double g = c[i];
+      for (int j = 0; j < n; j++) g += H[i * n + j] * xe[j];
+      double viol = st[i] < 0 ? -g : g;
+      if (viol > wd) { wd = viol; rel = i; }
+    }
+    if (rel >= 0) { st[rel] = 0; continue; }
+    for (int i = 0; i < n; i++) x[i] = xe[i];
+    return it + 1;
+  }
+  return -2;
+}
+
+static double audit_uniform(uint64_t* s) {   /* xorshift64*: uniform in [-1, 1) */
+  *s ^= *s >> 12; *s ^= *s << 25; *s ^= *s >> 27;
+  return (double)((*s * 2685821657736338717ull) >> 11) / 4503599627370496.0 - 1.0;
+}
+
+/* One retarget() call with the audit hooks.  qp_ptol > 0: every QP is solved by the relaxed-tolerance emulation;
+ * qp_noise > 0: every component of every QP solution is moved by an independent uniform amount in
+ * [-qp_noise, qp_noise] (a pessimistic stand-in for "any solver that is accurate to qp_noise").
+ * margins[0] = min over this frame's stop-rule decisions of |(curr - next) - tol| (motion_retarget.py:153,172);
+ * margins[1] = min over this frame's solves of the distance of a FREE limited joint's step from its bound
+ *              (how close an inactive bound is to switching);
+ * margins[2] = min over this frame's solves of |multiplier| of an ACTIVE bound (how close it is to releasing). */
+int orc_retarget_frame_audit(const gmr_model_t* m, const gmr_taskset_t* ts, double* q, const double* human,
+                             int offset_to_ground, double qp_ptol, double qp_noise, uint64_t* rng, int* nsolve,
+                             double* margins) {
+  double tgt[NHUM * 7], e[NK][6], H[NV * NV], c[NV], lo[NV], hi[NV], dq[NV];
+  orc_fk_t k;
+  const int nv = m->nv;
+  orc_preprocess(ts, human, offset_to_ground, tgt);
+  orc_fk(m, q, &k);
+  nsolve[0] = nsolve[1] = 0;
+  margins[0] = margins[1] = margins[2] = INFINITY;
+  for (int stage = 0; stage < 2; stage++) {
+    if (!ts->use_stage[stage]) continue;
+    double curr = orc_stage_error(m, ts, stage, &k, tgt, e);
+    int num_iter = 0;
+    for (;;) {
+      orc_build_qp(m, ts, stage, q, &k, e, H, c, lo, hi);
+      int rc = qp_ptol > 0.0 ? orc_solve_box_qp_relaxed(nv, H, c, lo, hi, qp_ptol, dq)
+                             : orc_solve_box_qp(nv, H, c, lo, hi, dq);
+      if (rc < 0) return -1;
+      for (int i = 6; i < nv; i++) {
+        if (!(lo[i] > -INFINITY)) continue;
+        const double gl = dq[i] - lo[i], gh = hi[i] - dq[i];
+        const double tolb = 1e-12 * (1.0 + fabs(lo[i]) + fabs(hi[i]));
+        if (gl > tolb && gh > tolb) {            /* free: distance to the nearer bound */
+          const double gmin = gl < gh ? gl : gh;
+          if (gmin < margins[1]) margins[1] = gmin;
+        } else {                                 /* on a bound: |multiplier| */
+          double g = c[i];
+          for (int j = 0; j < nv; j++) g += H[i * nv + j] * dq[j];
+          if (fabs(g) < margins[2]) margins[2] = fabs(g);
+        }
+      }
+      if (qp_noise > 0.0) for (int i = 0; i < nv; i++) dq[i] += qp_noise * audit_uniform(rng);
+      orc_integrate(m, q, dq);
+      orc_fk(m, q, &k);
+      double next = orc_stage_error(m, ts, stage, &k, tgt, e);
+      nsolve[stage]++;
+      if (nsolve[stage] > 1) num_iter++;
+      if (num_iter < ts->max_iter) {             /* the decision is the error test (not the iteration cap) */
+        const double mg = fabs((curr - next) - ts->tol);
+        if (mg < margins[0]) margins[0] = mg;
+      }
+      if (!(curr - next > ts->tol && num_iter < ts->max_iter)) break;
+      curr = next;
+    }
+  }
+  return 0;
+}
+
+/* margins[S][T][3] as in orc_retarget_frame_audit; stream s draws its noise from seed + s */
+void orc_retarget_streams_audit(const gmr_model_t* m, const gmr_taskset_t* ts, int S, int T, const double* q0,
+                                const double* human, int offset_to_ground, double qp_ptol, double qp_noise,
+                                uint64_t seed, double* q_out, int* nsolve, int* status, double* margins,
+                                int nthreads) {
+  int nq = m->nq, nh = ts->nhuman;
+  (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+  for (int s = 0; s < S; s++) {
+    double q[GMR_MAX_NQ + 1];
+    uint64_t rng = (seed + (uint64_t)s) * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull;
+    if (!rng) rng = 1;
+    memcpy(q, q0 + (size_t)s * nq, nq * sizeof(double));
+    status[s] = 0;
+    for (int t = 0; t < T; t++) {
+      size_t f = (size_t)s * T + t;
+      if (status[s] == 0) {
+        int rc = orc_retarget_frame_audit(m, ts, q, human + f * nh * 7, offset_to_ground, qp_ptol, qp_noise, &rng,
+                                          nsolve + 2 * f, margins + 3 * f);
+        if (rc < 0) status[s] = rc;
+      } else { nsolve[2 * f] = nsolve[2 * f + 1] = 0; margins[3 * f] = margins[3 * f + 1] = margins[3 * f + 2] = INFINITY; }
+      memcpy(q_out + f * nq, q, nq * sizeof(double));
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* H9: post-hoc batched FK, float32, KinematicsModel semantics                                  */
 /* (reference kinematics_model.py:172-182, 213-246; torch_utils.py:57-75,117-138,353-359)      */
 /* ------------------------------------------------------------------------------------------ */

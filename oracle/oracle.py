@@ -31,6 +31,7 @@ def lib():
             build()
         _lib = C.CDLL(_SO)
         _lib.orc_solve_box_qp.restype = C.c_int
+        _lib.orc_solve_box_qp_relaxed.restype = C.c_int
         _lib.orc_retarget_frame.restype = C.c_int
         _lib.orc_stage_error.restype = C.c_double
     return _lib
@@ -124,6 +125,32 @@ def retarget_streams(model, ts, q0, human, offset_to_ground=False, nthreads=1):
     lib().orc_retarget_streams(_p(model), _p(ts), S, T, _p(q0), _p(human), int(offset_to_ground), _p(q_out),
                                _p(ns), _p(st), int(nthreads))
     return q_out, ns, st
+
+
+def solve_box_qp_relaxed(H, c, lo, hi, ptol):
+    """DAQP-like termination: bounds violated by <= ptol stay out of the working set, x is not clipped."""
+    n = H.shape[0]
+    x = np.empty(n)
+    rc = lib().orc_solve_box_qp_relaxed(n, _p(_c(H, np.float64)), _p(_c(c, np.float64)), _p(_c(lo, np.float64)),
+                                        _p(_c(hi, np.float64)), C.c_double(float(ptol)), _p(x))
+    return x, rc
+
+
+def retarget_streams_audit(model, ts, q0, human, offset_to_ground=False, qp_ptol=0.0, qp_noise=0.0, seed=0, nthreads=1):
+    """retarget_streams with the parity-risk hooks: returns (q_out, nsolve, status, margins[S,T,3])
+    (margins: stop-rule margin, nearest inactive bound, smallest active multiplier; see gmr_oracle.c)."""
+    human = _c(human, np.float64)
+    S, T = human.shape[0], human.shape[1]
+    nq = int(model["nq"][0])
+    q0 = _c(q0, np.float64).reshape(S, nq)
+    q_out = np.empty((S, T, nq))
+    ns = np.zeros((S, T, 2), dtype=np.int32)
+    st = np.zeros(S, dtype=np.int32)
+    mg = np.empty((S, T, 3))
+    lib().orc_retarget_streams_audit(_p(model), _p(ts), S, T, _p(q0), _p(human), int(offset_to_ground),
+                                     C.c_double(float(qp_ptol)), C.c_double(float(qp_noise)), C.c_uint64(int(seed)),
+                                     _p(q_out), _p(ns), _p(st), _p(mg), int(nthreads))
+    return q_out, ns, st, mg
 
 
 def fk_f32(tree, root_pos, root_rot, dof):
