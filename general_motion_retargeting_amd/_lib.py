@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("GMR_HIP_LIBRARY") or os.path.join(_HERE, "libgmrhip.s
 _lib = None
 
 FLAG_OFFSET_TO_GROUND = 1
+FLAG_EVAL_ONLY = 2
 STATUS_OK, STATUS_QP_FAILED, STATUS_QP_MAXITER = 0, -1, -2
 
 
@@ -48,9 +49,9 @@ _SIGS = {
     "gmr_solver_set_waves": (C.c_int, [C.c_void_p, C.c_int]),
     "gmr_retarget_lds_bytes": (C.c_int, [C.c_void_p]),
     "gmr_retarget_streams_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gmr_retarget_streams": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gmr_fk_create": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.POINTER(C.c_void_p)]),
     "gmr_fk_destroy": (C.c_int, [C.c_void_p]),
@@ -136,6 +137,16 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def _s(stream):
+    """hipStream_t of a :class:`Stream`, a raw ``c_void_p`` or ``None`` (the default stream)."""
+    return stream.ptr if isinstance(stream, Stream) else stream
+
+
+def _d(x):
+    """device pointer of a :class:`DeviceBuffer`, a raw ``c_void_p`` or ``None``."""
+    return x.ptr if isinstance(x, DeviceBuffer) else x
+
+
 class DeviceBuffer:
     """Owned device allocation (hipMalloc through the C-ABI)."""
 
@@ -149,7 +160,7 @@ class DeviceBuffer:
     def from_host(cls, a: np.ndarray, stream=None) -> "DeviceBuffer":
         a = np.ascontiguousarray(a)
         b = cls(a.nbytes)
-        s = stream.ptr if isinstance(stream, Stream) else stream
+        s = _s(stream)
         check(lib().gmr_memcpy_h2d(b.ptr, _ptr(a), a.nbytes, s))
         check(lib().gmr_stream_sync(s))
         return b
@@ -157,7 +168,7 @@ class DeviceBuffer:
     def to_host(self, shape, dtype, stream=None) -> np.ndarray:
         out = np.empty(shape, dtype=dtype)
         assert out.nbytes <= self.nbytes
-        s = stream.ptr if isinstance(stream, Stream) else stream
+        s = _s(stream)
         check(lib().gmr_memcpy_d2h(_ptr(out), self.ptr, out.nbytes, s))
         check(lib().gmr_stream_sync(s))
         return out
@@ -200,7 +211,7 @@ class Event:
         self.ptr = p
 
     def record(self, stream=None):
-        check(lib().gmr_event_record(self.ptr, stream))
+        check(lib().gmr_event_record(self.ptr, _s(stream)))
 
     def elapsed_ms(self, stop: "Event") -> float:
         ms = C.c_float()
@@ -238,8 +249,11 @@ class Solver:
     def lds_bytes(self) -> int:
         return int(lib().gmr_retarget_lds_bytes(self.handle))
 
-    def retarget_streams(self, q0, human, lens=None, flags: int = 0):
-        """Host arrays in/out: q0[S,nq], human[S,T,nhuman,7] -> q_out[S,T,nq], nsolve[S,T,2], status[S]."""
+    def retarget_streams(self, q0, human, lens=None, flags: int = 0, want_targets: bool = False,
+                         want_errors: bool = False):
+        """Host arrays in/out: q0[S,nq], human[S,T,nhuman,7] -> q_out[S,T,nq], nsolve[S,T,2], status[S]
+        (+ targets[S,T,nhuman,7] = the kernel's preprocessed frames and/or errors[S,T,2] = error1/error2 at the
+        configuration every frame ends with, when asked for)."""
         human = np.ascontiguousarray(human, dtype=np.float64)
         if human.ndim != 4 or human.shape[2] != self.nhuman or human.shape[3] != 7:
             raise ValueError(f"human must be [S,T,{self.nhuman},7], got {human.shape}")
@@ -254,17 +268,20 @@ class Solver:
         q_out = np.zeros((S, T, self.nq), dtype=np.float64)
         nsolve = np.zeros((S, T, 2), dtype=np.int32)
         status = np.zeros(S, dtype=np.int32)
+        targets = np.zeros((S, T, self.nhuman, 7), dtype=np.float64) if want_targets else None
+        errors = np.zeros((S, T, 2), dtype=np.float64) if want_errors else None
         check(lib().gmr_retarget_streams(self.handle, S, T, _ptr(q0), _ptr(human), _ptr(lens), int(flags),
-                                         _ptr(q_out), _ptr(nsolve), _ptr(status)))
+                                         _ptr(q_out), _ptr(nsolve), _ptr(status), _ptr(targets), _ptr(errors)))
+        if want_targets or want_errors:
+            return q_out, nsolve, status, targets, errors
         return q_out, nsolve, status
 
-    def retarget_streams_dev(self, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream=None):
+    def retarget_streams_dev(self, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream=None,
+                             d_tgt_out=None, d_err_out=None):
         """Device pointers (DeviceBuffer or raw c_void_p); asynchronous on `stream`."""
-        def p(x):
-            return x.ptr if isinstance(x, DeviceBuffer) else x
-        s = stream.ptr if isinstance(stream, Stream) else stream
-        check(lib().gmr_retarget_streams_dev(self.handle, int(S), int(T), p(d_q0), p(d_human), p(d_len), int(flags),
-                                             p(d_q_out), p(d_nsolve), p(d_status), s))
+        check(lib().gmr_retarget_streams_dev(self.handle, int(S), int(T), _d(d_q0), _d(d_human), _d(d_len), int(flags),
+                                             _d(d_q_out), _d(d_nsolve), _d(d_status), _d(d_tgt_out), _d(d_err_out),
+                                             _s(stream)))
 
     def close(self):
         if self.handle:
@@ -308,10 +325,8 @@ class FkHandle:
         return bp, br, (float(mz[0]) if want_min_z else None)
 
     def fk_dev(self, B, d_root_pos, d_root_rot, d_dof, d_body_pos, d_body_rot=None, d_min_z=None, stream=None):
-        def p(x):
-            return x.ptr if isinstance(x, DeviceBuffer) else x
-        check(lib().gmr_fk_batch_dev(self.handle, int(B), p(d_root_pos), p(d_root_rot), p(d_dof), p(d_body_pos),
-                                     p(d_body_rot), p(d_min_z), stream))
+        check(lib().gmr_fk_batch_dev(self.handle, int(B), _d(d_root_pos), _d(d_root_rot), _d(d_dof), _d(d_body_pos),
+                                     _d(d_body_rot), _d(d_min_z), _s(stream)))
 
     def close(self):
         if self.handle:
@@ -364,15 +379,12 @@ class SmplxHandle:
         return out
 
     def align_dev(self, N, jstride, d_full_pose, d_joints, nout, d_target_time, d_out, stream=None):
-        def p(x):
-            return x.ptr if isinstance(x, DeviceBuffer) else x
-        check(lib().gmr_smplx_align_dev(self.handle, int(N), int(jstride), p(d_full_pose), p(d_joints), int(nout),
-                                        p(d_target_time), p(d_out), stream))
+        check(lib().gmr_smplx_align_dev(self.handle, int(N), int(jstride), _d(d_full_pose), _d(d_joints), int(nout),
+                                        _d(d_target_time), _d(d_out), _s(stream)))
 
     def joints_dev(self, N, d_j_rest, d_full_pose, d_transl, d_joints, stream=None):
-        def p(x):
-            return x.ptr if isinstance(x, DeviceBuffer) else x
-        check(lib().gmr_smplx_joints_dev(self.handle, int(N), p(d_j_rest), p(d_full_pose), p(d_transl), p(d_joints), stream))
+        check(lib().gmr_smplx_joints_dev(self.handle, int(N), _d(d_j_rest), _d(d_full_pose), _d(d_transl), _d(d_joints),
+                                         _s(stream)))
 
     def close(self):
         if self.handle:

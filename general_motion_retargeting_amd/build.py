@@ -8,8 +8,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgmrhip.so")
-SOURCES = ["gmr_ik.hip", "gmr_fk.hip", "gmr_smplx.hip", "gmr_abi.hip"]
-HEADERS = ["gmr_device_math.h", "gmr_ik_layout.h", "gmr_ik_tree.h", "gmr_fk_tree.h", "gmr_internal.h", "../../include/gmr_hip.h",
+SOURCES = ["gmr_ik.hip", "gmr_ik_wide.hip", "gmr_fk.hip", "gmr_smplx.hip", "gmr_abi.hip"]
+HEADERS = ["gmr_device_math.h", "gmr_ik_layout.h", "gmr_ik_wide_layout.h", "gmr_ik_prof.h", "gmr_ik_tree.h", "gmr_fk_tree.h", "gmr_internal.h", "../../include/gmr_hip.h",
            "../../include/gmr_types.h"]
 
 

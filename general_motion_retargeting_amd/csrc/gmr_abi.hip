@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -12,6 +13,7 @@
 #include "../../include/gmr_hip.h"
 #include "gmr_fk_tree.h"
 #include "gmr_ik_layout.h"
+#include "gmr_ik_wide_layout.h"
 #include "gmr_internal.h"
 
 static_assert(sizeof(gmr_model_t) % 8 == 0, "gmr_model_t must be 8-byte sized");
@@ -21,8 +23,12 @@ static_assert(offsetof(gmr_taskset_t, damping) % 8 == 0, "double block of gmr_ta
 
 extern "C" hipError_t gmr_launch_ik_streams(const uint4*, const gmr::IkLayout*, const gmr::IkParams*, int, int,
                                             const double*, const double*, const int32_t*, int, double*, int32_t*,
-                                            int32_t*, hipStream_t, unsigned long long*);
+                                            int32_t*, double*, double*, hipStream_t, unsigned long long*);
 extern "C" hipError_t gmr_ik_set_max_smem(int nvp, int nw, int tree_small, int bytes);
+extern "C" hipError_t gmr_launch_ik_wide(const char*, const gmr::WideLayout*, const gmr::IkParams*, int, int, const double*,
+                                         const double*, const int32_t*, int, double*, int32_t*, int32_t*, double*, double*,
+                                         hipStream_t, unsigned long long*);
+extern "C" hipError_t gmr_ik_wide_attributes(int* num_regs, int* lds_bytes, int* max_waves_per_cu);
 extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree*, int, int, int, const float*, const float*, const float*,
                                           float*, float*, float*, float*, hipStream_t);
 extern "C" int gmr_fk_blocks(int nbody, int B);
@@ -60,6 +66,8 @@ struct gmr_solver {
   int force_waves = 0;           // 0 = choose by stream count, 1 or 4 = forced (gmr_solver_set_waves)
   gmr::IkParams params;
   uint4* d_image = nullptr;      // host-built LDS image of the constants (gmr_ik_layout.h)
+  gmr::WideLayout wide;          // throughput shape (gmr_ik_wide.hip): ok = 0 when the robot does not fit it
+  char* d_wide = nullptr;        // its global image of the constants
   char* ws = nullptr;            // grow-only device workspace of the host-buffer entry point
   size_t ws_bytes = 0;
   char* pin = nullptr;           // pinned host staging for small calls (one H2D + one D2H per call)
@@ -218,9 +226,19 @@ int gmr_solver_create(const gmr_model_t* model, const gmr_taskset_t* taskset, gm
     if ((e = hipMemcpy(*dst, img.data(), img.size(), hipMemcpyHostToDevice)) != hipSuccess) break;
     e = gmr_ik_set_max_smem(lay.nvp, nw, lay.tree_small, lay.smem_bytes);
   }
+  s->wide = gmr::WideLayout{};
+  if (e == hipSuccess && !getenv("GMR_IK_NO_WIDE")) {   // (diagnostic switch: A/B against the one-wavefront kernel of gmr_ik.hip)
+    std::vector<char> img;
+    s->wide = gmr::make_wide_layout(s->model, s->ts, &img);
+    if (s->wide.ok) {
+      if ((e = hipMalloc((void**)&s->d_wide, img.size())) == hipSuccess)
+        e = hipMemcpy(s->d_wide, img.data(), img.size(), hipMemcpyHostToDevice);
+    }
+  }
   if (e != hipSuccess) {
     if (s->d_image) (void)hipFree(s->d_image);
     if (s->d_image4) (void)hipFree(s->d_image4);
+    if (s->d_wide) (void)hipFree(s->d_wide);
     delete s;
     return fail(GMR_ERR_HIP, "gmr_solver_create: %s", hipGetErrorString(e));
   }
@@ -232,6 +250,7 @@ int gmr_solver_destroy(gmr_solver_t* s) {
   if (!s) return GMR_OK;
   (void)hipFree(s->d_image);
   (void)hipFree(s->d_image4);
+  if (s->d_wide) (void)hipFree(s->d_wide);
   if (s->ws) (void)hipFree(s->ws);
   if (s->pin) (void)hipHostFree(s->pin);
   delete s;
@@ -258,7 +277,7 @@ int gmr_retarget_lds_bytes(const gmr_solver_t* s) { return s ? s->layout4.smem_b
 
 int gmr_retarget_streams_dev(gmr_solver_t* s, int S, int T, const double* d_q0, const double* d_human,
                              const int32_t* d_len, int flags, double* d_q_out, int32_t* d_nsolve,
-                             int32_t* d_status, void* stream) {
+                             int32_t* d_status, double* d_tgt_out, double* d_err_out, void* stream) {
   if (!s) return fail(GMR_ERR_ARG, "null solver");
   if (S < 0 || T < 0) return fail(GMR_ERR_ARG, "negative S/T");
   if (S == 0 || T == 0) return GMR_OK;
@@ -266,8 +285,13 @@ int gmr_retarget_streams_dev(gmr_solver_t* s, int S, int T, const double* d_q0, 
   // few streams: 4 waves per stream (helpers share the wide assembly phases, shorter per-frame
   // latency); many streams: 1 wave per stream (more streams resident, more frames per second)
   const bool wide = s->layout4.tree_ok && (s->force_waves ? s->force_waves == 4 : S <= GMR_HELPER_MAX_STREAMS);
-  HIP_TRY(gmr_launch_ik_streams(wide ? s->d_image4 : s->d_image, wide ? &s->layout4 : &s->layout, &s->params, S, T,
-                                d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, (hipStream_t)stream, nullptr));
+  if (!wide && s->wide.ok)     // throughput shape: two resident wavefronts per SIMD (gmr_ik_wide.hip)
+    HIP_TRY(gmr_launch_ik_wide(s->d_wide, &s->wide, &s->params, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve,
+                               d_status, d_tgt_out, d_err_out, (hipStream_t)stream, nullptr));
+  else
+    HIP_TRY(gmr_launch_ik_streams(wide ? s->d_image4 : s->d_image, wide ? &s->layout4 : &s->layout, &s->params, S, T,
+                                  d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, d_tgt_out, d_err_out,
+                                  (hipStream_t)stream, nullptr));
   return GMR_OK;
 }
 
@@ -276,14 +300,18 @@ int gmr_retarget_streams_dev(gmr_solver_t* s, int S, int T, const double* d_q0, 
 int gmr_retarget_streams_prof(gmr_solver_t* s, int S, int T, const double* d_q0, const double* d_human, int flags,
                               double* d_q_out, int32_t* d_nsolve, int32_t* d_status, unsigned long long* d_prof) {
   const bool wide = s->layout4.tree_ok && (s->force_waves ? s->force_waves == 4 : S <= GMR_HELPER_MAX_STREAMS);
-  HIP_TRY(gmr_launch_ik_streams(wide ? s->d_image4 : s->d_image, wide ? &s->layout4 : &s->layout, &s->params, S, T,
-                                d_q0, d_human, nullptr, flags, d_q_out, d_nsolve, d_status, nullptr, d_prof));
+  if (!wide && s->wide.ok)
+    HIP_TRY(gmr_launch_ik_wide(s->d_wide, &s->wide, &s->params, S, T, d_q0, d_human, nullptr, flags, d_q_out, d_nsolve,
+                               d_status, nullptr, nullptr, nullptr, d_prof));
+  else
+    HIP_TRY(gmr_launch_ik_streams(wide ? s->d_image4 : s->d_image, wide ? &s->layout4 : &s->layout, &s->params, S, T,
+                                  d_q0, d_human, nullptr, flags, d_q_out, d_nsolve, d_status, nullptr, nullptr, nullptr, d_prof));
   return GMR_OK;
 }
 #endif
 
 int gmr_retarget_streams(gmr_solver_t* s, int S, int T, const double* q0, const double* human, const int32_t* len,
-                         int flags, double* q_out, int32_t* nsolve, int32_t* status) {
+                         int flags, double* q_out, int32_t* nsolve, int32_t* status, double* tgt_out, double* err_out) {
   if (!s) return fail(GMR_ERR_ARG, "null solver");
   if (S < 0 || T < 0) return fail(GMR_ERR_ARG, "negative S/T");
   if (S == 0 || T == 0) return GMR_OK;
@@ -291,9 +319,10 @@ int gmr_retarget_streams(gmr_solver_t* s, int S, int T, const double* q0, const 
   const size_t nq = s->model.nq, nh = s->ts.nhuman;
   const size_t b_q0 = (size_t)S * nq * 8, b_h = (size_t)S * T * nh * 7 * 8, b_qo = (size_t)S * T * nq * 8;
   const size_t b_ns = (size_t)S * T * 2 * 4, b_st = (size_t)S * 4, b_len = (size_t)S * 4;
+  const size_t b_tg = tgt_out ? b_h : 0, b_er = err_out ? (size_t)S * T * 2 * 8 : 0;
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   size_t o_q0 = 0, o_h = o_q0 + up(b_q0), o_len = o_h + up(b_h), o_qo = o_len + up(b_len), o_ns = o_qo + up(b_qo),
-         o_st = o_ns + up(b_ns), total = o_st + up(b_st);
+         o_st = o_ns + up(b_ns), o_tg = o_st + up(b_st), o_er = o_tg + up(b_tg), total = o_er + up(b_er);
   // grow-only workspace kept on the handle: a per-frame caller (retarget() once per frame) pays no
   // hipMalloc/hipFree per call.  Like the reference object, a handle is not re-entrant on this path.
   if (total > s->ws_bytes) {
@@ -307,7 +336,7 @@ int gmr_retarget_streams(gmr_solver_t* s, int S, int T, const double* q0, const 
   char* d = s->ws;
   int rc = GMR_OK;
   hipError_t e;
-  // inputs are laid out [q0 | human | len | q_out | nsolve | status]; small calls (the per-frame
+  // buffers are laid out [q0 | human | len | q_out | nsolve | status | tgt_out | err_out]; small calls (the per-frame
   // API) go through pinned staging so that a call is 1 H2D + 1 launch + 1 D2H + 1 sync
   const size_t in_bytes = o_qo, out_bytes = total - o_qo;
   const bool small = total <= gmr_solver::kPinBytes;
@@ -328,7 +357,8 @@ int gmr_retarget_streams(gmr_solver_t* s, int S, int T, const double* q0, const 
     rc = fail(GMR_ERR_HIP, "memset: %s", hipGetErrorString(e));
   if (rc == GMR_OK)
     rc = gmr_retarget_streams_dev(s, S, T, (double*)(d + o_q0), (double*)(d + o_h), len ? (int32_t*)(d + o_len) : nullptr,
-                                  flags, (double*)(d + o_qo), (int32_t*)(d + o_ns), (int32_t*)(d + o_st), nullptr);
+                                  flags, (double*)(d + o_qo), (int32_t*)(d + o_ns), (int32_t*)(d + o_st),
+                                  tgt_out ? (double*)(d + o_tg) : nullptr, err_out ? (double*)(d + o_er) : nullptr, nullptr);
   if (rc == GMR_OK && small) {
     if ((e = hipMemcpyAsync(s->pin + o_qo, d + o_qo, out_bytes, hipMemcpyDeviceToHost, nullptr)) != hipSuccess ||
         (e = hipStreamSynchronize(nullptr)) != hipSuccess)
@@ -337,11 +367,15 @@ int gmr_retarget_streams(gmr_solver_t* s, int S, int T, const double* q0, const 
       memcpy(q_out, s->pin + o_qo, b_qo);
       memcpy(nsolve, s->pin + o_ns, b_ns);
       memcpy(status, s->pin + o_st, b_st);
+      if (tgt_out) memcpy(tgt_out, s->pin + o_tg, b_tg);
+      if (err_out) memcpy(err_out, s->pin + o_er, b_er);
     }
   } else if (rc == GMR_OK) {
     if ((e = hipMemcpyAsync(q_out, d + o_qo, b_qo, hipMemcpyDeviceToHost, nullptr)) != hipSuccess ||
         (e = hipMemcpyAsync(nsolve, d + o_ns, b_ns, hipMemcpyDeviceToHost, nullptr)) != hipSuccess ||
         (e = hipMemcpyAsync(status, d + o_st, b_st, hipMemcpyDeviceToHost, nullptr)) != hipSuccess ||
+        (tgt_out && (e = hipMemcpyAsync(tgt_out, d + o_tg, b_tg, hipMemcpyDeviceToHost, nullptr)) != hipSuccess) ||
+        (err_out && (e = hipMemcpyAsync(err_out, d + o_er, b_er, hipMemcpyDeviceToHost, nullptr)) != hipSuccess) ||
         (e = hipStreamSynchronize(nullptr)) != hipSuccess)
       rc = fail(GMR_ERR_HIP, "kernel / D2H copy: %s", hipGetErrorString(e));
   }

@@ -42,6 +42,7 @@
 #include "../../include/gmr_hip.h"
 #include "gmr_device_math.h"
 #include "gmr_ik_layout.h"
+#include "gmr_ik_prof.h"
 
 namespace gmr {
 
@@ -61,28 +62,6 @@ __device__ __forceinline__ void wsync() {
 #endif
 enum { QP_DENSE = 0, QP_TREE_SMALL = 1, QP_TREE = 2 };   // solver carried by a kernel instance
 enum { CMD_BUILD = 1, CMD_EXIT = 2, CMD_JBODY = 3 };   // BUILD: assemble the QP, then solve it together; JBODY: body Jacobians
-
-// Diagnostic phase timer (GMR_IK_PROFILE builds only; never in the shipped kernel): s_memtime
-// stamps accumulated per phase, written to a buffer no other code reads.
-enum { PH_PRE, PH_FK, PH_ERR, PH_JLOG, PH_PAIRS, PH_CVEC, PH_HACC, PH_KBUILD, PH_CHOL, PH_SUBST, PH_RATIO,
-       PH_MULT, PH_INTEG, PH_IO, PH_NFACT, PH_NSOLVE, PH_TICKS, PH_REALTIME, PH_COUNT };
-#ifdef GMR_IK_PROFILE
-struct Prof {
-  unsigned long long acc[PH_COUNT];
-  unsigned long long t0;
-  __device__ __forceinline__ void begin() { t0 = __builtin_amdgcn_s_memtime(); }
-  __device__ __forceinline__ void end(int ph) { acc[ph] += __builtin_amdgcn_s_memtime() - t0; }
-  __device__ __forceinline__ void count(int ph) { acc[ph] += 1; }
-};
-#define PROF_BEGIN(p) (p).begin()
-#define PROF_END(p, ph) (p).end(ph)
-#define PROF_COUNT(p, ph) (p).count(ph)
-#else
-struct Prof {};
-#define PROF_BEGIN(p)
-#define PROF_END(p, ph)
-#define PROF_COUNT(p, ph)
-#endif
 
 // value of lane `src` (wave-uniform index) as a scalar operand
 __device__ __forceinline__ double readlane_d(double v, int src) {
@@ -819,6 +798,8 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
                                                              double* __restrict__ q_out,
                                                              int32_t* __restrict__ nsolve,
                                                              int32_t* __restrict__ status,
+                                                             double* __restrict__ tgt_out,
+                                                             double* __restrict__ err_out,
                                                              unsigned long long* __restrict__ prof_out) {
   extern __shared__ __align__(16) double smem[];
   const int wave = threadIdx.x >> 6;
@@ -891,10 +872,13 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
     }
     WSYNC();
     int ns0 = 0, ns1 = 0;
+    const size_t f = (size_t)s * T + t;
     if (stat == GMR_STATUS_OK) {
       preprocess_wave<NW>(L, sm, is_foot, human_root, prm[4], flags, lane, pr);
+      if (tgt_out)     // the poses handed to task.set_target (motion_retarget.py:117-136) = scaled_human_data
+        for (int i = lane; i < (int)fstride; i += 64) tgt_out[f * fstride + i] = (sm + L.o.tgt)[i];
       for (int stage = 0; stage < 2; stage++) {
-        if (!(stage == 0 ? use0 : use1)) continue;
+        if (!(stage == 0 ? use0 : use1) || (flags & GMR_FLAG_EVAL_ONLY)) continue;
         const StageTabs tb = {si + L.o.i_task_body[stage], si + L.o.i_task_human[stage], si + L.o.i_pair_task[stage],
                               si + L.o.i_pair_dof[stage], si + L.o.i_pair_index[stage],
                               NW == 1 ? reinterpret_cast<const uint32_t*>(image) + L.g_items[stage] : sw + L.w_items[stage]};
@@ -945,7 +929,16 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
         if (stat != GMR_STATUS_OK) break;
       }
     }
-    const size_t f = (size_t)s * T + t;
+    if (err_out && stat == GMR_STATUS_OK) {
+      // error1() / error2() of the reference (motion_retarget.py:188-200): both tables' residual norms at the
+      // configuration this frame ends with (only evaluated when the caller asks: the per-frame API)
+      for (int stage = 0; stage < 2; stage++) {
+        double E = 0.0;
+        if (stage == 0 ? use0 : use1)
+          E = errors_wave<NW>(L, sm, si + L.o.i_task_body[stage], si + L.o.i_task_human[stage], L.K[stage], lane, pr);
+        if (lane == 0) err_out[2 * f + stage] = E;
+      }
+    }
     for (int i = lane; i < nq; i += 64) q_out[f * nq + i] = (sm + L.o.q)[i];
     if (lane == 0) { nsolve[2 * f] = ns0; nsolve[2 * f + 1] = ns1; }
     WSYNC();
@@ -976,13 +969,14 @@ template <int NVP, int NW, int QP>
 static hipError_t launch_nvp(const uint4* d_image, const gmr::IkLayout* L, const gmr::IkParams* P, int S, int T,
                              const double* d_q0, const double* d_human,
                              const int32_t* d_len, int flags, double* d_q_out, int32_t* d_nsolve, int32_t* d_status,
-                             hipStream_t stream, unsigned long long* d_prof) {
+                             double* d_tgt_out, double* d_err_out, hipStream_t stream, unsigned long long* d_prof) {
   hipLaunchKernelGGL((gmr::ik_streams_kernel<NVP, NW, QP>), dim3(S), dim3(64 * NW), L->smem_bytes, stream, d_image,
-                     gmr::IkLay<NVP, NW>(static_cast<const gmr::IkDims&>(*L)), *P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, d_prof);
+                     gmr::IkLay<NVP, NW>(static_cast<const gmr::IkDims&>(*L)), *P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status,
+                     d_tgt_out, d_err_out, d_prof);
   return hipGetLastError();
 }
 
-#define GMR_ARGS d_image, L, P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, stream, d_prof
+#define GMR_ARGS d_image, L, P, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, d_tgt_out, d_err_out, stream, d_prof
 #define GMR_DISPATCH(NVP_)                                                                             \
   case NVP_:                                                                                           \
     if (L->nw == 1) return L->tree_small ? launch_nvp<NVP_, 1, gmr::QP_TREE_SMALL>(GMR_ARGS)           \
@@ -993,7 +987,8 @@ static hipError_t launch_nvp(const uint4* d_image, const gmr::IkLayout* L, const
 extern "C" hipError_t gmr_launch_ik_streams(const uint4* d_image, const gmr::IkLayout* L, const gmr::IkParams* P,
                                             int S, int T, const double* d_q0, const double* d_human,
                                             const int32_t* d_len, int flags, double* d_q_out, int32_t* d_nsolve,
-                                            int32_t* d_status, hipStream_t stream, unsigned long long* d_prof) {
+                                            int32_t* d_status, double* d_tgt_out, double* d_err_out,
+                                            hipStream_t stream, unsigned long long* d_prof) {
   if (S <= 0 || T <= 0) return hipSuccess;
   switch (L->nvp) {
     GMR_DISPATCH(28)

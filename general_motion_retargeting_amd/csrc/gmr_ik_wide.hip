@@ -1,0 +1,771 @@
+// gmr_ik_wide.hip -- the THROUGHPUT shape of the retargeting kernel (rows H2-H7 of SURVEY.md section 8a): one
+// 64-lane wavefront per motion stream, 22 KB of LDS per stream and <= 256 registers, so that TWO wavefronts are
+// resident per SIMD (seven streams per CU) where the kernel of gmr_ik.hip holds one (four streams per CU).
+//
+// Same algorithm, same lane mappings and the same arithmetic as the one-wavefront instance of gmr_ik.hip (see the
+// header there); what differs is where things live (gmr_ik_wide_layout.h):
+//   global image   everything that is the same for every stream -- joint-local transforms, limits, task and pair
+//                  tables, tree tables, parameters, the H-assembly schedule -- read per phase with a few coalesced
+//                  per-lane loads (the image is a few KB: vector-L1 / L2 resident, shared by the CU's streams)
+//   LDS state      q, FK result, world hinge axes, targets; H in the block-arrowhead form the solver consumes
+//                  (four 16 x 7 matrices [D_l; B_l] + the 9 x 9 trunk block), c, bounds, x
+//   LDS scratch    residuals, -Jl^-1 blocks, weighted Jacobian columns; the solver's transposes and Schur parts
+//                  alias them
+// The box-QP is the tree-structured solver of gmr_ik_tree.h in its one-wavefront form (the four limbs in the four
+// 16-lane DPP rows), reading H rows as contiguous 56-byte pieces and keeping the bound sets in LANE coordinates
+// (bit = the lane that owns the variable), so that no dof tables are consulted inside a pivoting round.
+//
+// Used for every robot that decomposes into <= 4 limbs of <= 7 dofs and a trunk of <= 9 (all shipped robots) when a
+// launch has more streams than the latency shape pays off for (gmr_abi.hip).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/gmr_hip.h"
+#include "gmr_device_math.h"
+#include "gmr_ik_prof.h"
+#include "gmr_ik_wide_layout.h"
+
+#ifndef GMR_WIDE_MIN_WAVES
+#define GMR_WIDE_MIN_WAVES 2
+#endif
+
+namespace gmr {
+namespace wide {
+
+constexpr WideLds LD = wide_lds();
+constexpr WideImg IM = wide_img();
+
+// one wavefront per workgroup: LDS operations of a wave execute in order, the barrier degenerates to the wait
+__device__ __forceinline__ void wsync() { __syncthreads(); }
+
+template <class T>
+__device__ __forceinline__ const T* img_at(const char* img, int byte_off) {
+  return reinterpret_cast<const T*>(img + byte_off);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FK: mj_kinematics semantics (App. A.3) by pointer jumping, lane = body (see fk_wave in gmr_ik.hip)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fk_wide(const WideDims& D, double* sm, const char* __restrict__ img, int lane, Prof& pr) {
+  PROF_BEGIN(pr);
+  const int nb = D.nb;
+  double* q = sm + LD.q;
+  d3 pos = {0, 0, 0}, ax = {0, 0, 0};
+  d4 quat = {1, 0, 0, 0};
+  uint32_t hops = 0;
+  int dep = 0, hinge = -1;
+  if (lane < nb) {
+    const uint2 ci = img_at<uint2>(img, IM.fki)[lane];
+    hops = ci.x; dep = ci.y & 255u; hinge = (int)(ci.y >> 8) - 1;
+    if (lane == 0) {
+      quat = qnormalize(d4{q[3], q[4], q[5], q[6]});
+      q[3] = quat.w; q[4] = quat.x; q[5] = quat.y; q[6] = quat.z;
+      pos = d3{q[0], q[1], q[2]};
+    } else {
+      const double* c = img_at<double>(img, IM.fkc) + 10 * lane;
+      pos = d3{c[0], c[1], c[2]};
+      quat = d4{c[3], c[4], c[5], c[6]};
+      if (hinge >= 0) {
+        ax = d3{c[7], c[8], c[9]};
+        const double* sc = sm + LD.hsc + 2 * hinge;     // sin, cos of q[7 + h] / 2 (hinge_sincos / integrate)
+        const double s = sc[0], cs = sc[1];
+        quat = qmul(quat, d4{cs, ax.x * s, ax.y * s, ax.z * s});
+      }
+    }
+  }
+  for (int r = 0; r < D.nhop; r++) {
+    double* wb = sm + ((r & 1) ? LD.xa : LD.xb);
+    if (lane < nb) {
+      double* o = wb + 7 * lane;
+      o[0] = pos.x; o[1] = pos.y; o[2] = pos.z; o[3] = quat.w; o[4] = quat.x; o[5] = quat.y; o[6] = quat.z;
+    }
+    wsync();
+    if (lane < nb && dep >= (1 << r)) {
+      const double* a = wb + 7 * ((hops >> (6 * r)) & 63u);
+      d4 qa = {a[3], a[4], a[5], a[6]};
+      pos = d3{a[0], a[1], a[2]} + qrot(qa, pos);
+      quat = qmul(qa, quat);
+    }
+  }
+  if (D.nhop > 0 && ((D.nhop - 1) & 1)) wsync();       // the last round read from xa
+  if (lane < nb) {
+    quat = qnormalize(quat);
+    double* o = sm + LD.xa + 7 * lane;
+    o[0] = pos.x; o[1] = pos.y; o[2] = pos.z; o[3] = quat.w; o[4] = quat.x; o[5] = quat.y; o[6] = quat.z;
+    if (hinge >= 0) {
+      d3 aw = qrot(quat, ax);
+      double* xa = sm + LD.xaxis + 3 * lane;
+      xa[0] = aw.x; xa[1] = aw.y; xa[2] = aw.z;
+    }
+  }
+  wsync();
+  PROF_END(pr, PH_FK);
+}
+
+// residuals of the stage's tasks and their unweighted norm (motion_retarget.py:188-200); lane = task
+__device__ __forceinline__ double errors_wide(double* sm, uint32_t taskw, int K, int lane, Prof& pr) {
+  PROF_BEGIN(pr);
+  double ss = 0.0;
+  if (lane < K) {
+    const int b = taskw & 255u, h = taskw >> 8;
+    const double* x = sm + LD.xa + 7 * b;
+    const double* tg = sm + LD.tgt + 7 * h;
+    double e[6], aux[3];
+    se3_log_rel(d3{x[0], x[1], x[2]}, d4{x[3], x[4], x[5], x[6]}, d3{tg[0], tg[1], tg[2]},
+                d4{tg[3], tg[4], tg[5], tg[6]}, e, aux);
+    double* eo = sm + LD.e + 6 * lane;
+#pragma unroll
+    for (int r = 0; r < 6; r++) { eo[r] = e[r]; ss += e[r] * e[r]; }
+    double* ao = sm + LD.eaux + 3 * lane;
+    ao[0] = aux[0]; ao[1] = aux[1]; ao[2] = aux[2];
+  }
+  ss = row0_sum(ss);
+  wsync();
+  PROF_END(pr, PH_ERR);
+  return sqrt(ss);
+}
+
+// (a) lane = task: M_k = -Jl^-1(e_k); returns the LM term mu
+__device__ __forceinline__ double jlog_wide(double* sm, const char* __restrict__ img, int stage, int K, double lm_damping,
+                                            int lane, Prof& pr) {
+  PROF_BEGIN(pr);
+  double mu = 0.0;
+  if (lane < K) {
+    const double* w = img_at<double>(img, IM.task[stage]) + 2 * lane;
+    const double wp = w[0], wr = w[1];
+    const double* e = sm + LD.e + 6 * lane;
+    double ee[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) ee[r] = e[r];
+    const double* ax = sm + LD.eaux + 3 * lane;
+    const double aux[3] = {ax[0], ax[1], ax[2]};
+    m3 A, B;
+    se3_jlinv_aux(ee, aux, A, B);
+    double* M = sm + LD.M + 18 * lane;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { M[i] = -A.a[i]; M[9 + i] = -B.a[i]; }
+    double* wt = sm + LD.wts + 2 * lane;
+    wt[0] = wp; wt[1] = wr;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      double v = (r < 3 ? wp : wr) * ee[r];
+      mu += v * v;
+    }
+  }
+  mu = lm_damping * row0_sum(mu);
+  wsync();                                             // (eaux is dead from here: the column phase overwrites it)
+  PROF_END(pr, PH_JLOG);
+  return mu;
+}
+
+// (b) virtual lane = (task, dof) pair: weighted task-Jacobian column W_k (-Jl^-1(e_k)) J_body[:, d]
+__device__ __forceinline__ void pairs_wide(double* sm, const char* __restrict__ img, int stage, int P, int lane) {
+  double* Jw = sm + LD.Jw;
+  double* cpart = sm + LD.cpart;
+  const double* X = sm + LD.xa;
+  const uint32_t* pw = img_at<uint32_t>(img, IM.pair[stage]);
+  for (int p = lane; p < P; p += 64) {
+    const uint32_t info = pw[p];                        // [3:0] task, [9:4] dof, [15:10] task body, [21:16] hinge body
+    const int k = info & 15u, dof = (info >> 4) & 63u, b = (info >> 10) & 63u, c = (info >> 16) & 63u;
+    d3 pb = {X[7 * b], X[7 * b + 1], X[7 * b + 2]};
+    d4 qb = {X[7 * b + 3], X[7 * b + 4], X[7 * b + 5], X[7 * b + 6]};
+    d3 lin, ang;
+    if (dof < 3) {
+      lin = d3{dof == 0 ? 1.0 : 0.0, dof == 1 ? 1.0 : 0.0, dof == 2 ? 1.0 : 0.0};
+      ang = d3{0.0, 0.0, 0.0};
+    } else if (dof < 6) {
+      d4 q0 = {X[3], X[4], X[5], X[6]};
+      int a = dof - 3;
+      ang = qrot(q0, d3{a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0});
+      lin = cross(ang, pb - d3{X[0], X[1], X[2]});
+    } else {
+      const double* xa = sm + LD.xaxis + 3 * c;
+      ang = d3{xa[0], xa[1], xa[2]};
+      lin = cross(ang, pb - d3{X[7 * c], X[7 * c + 1], X[7 * c + 2]});
+    }
+    d3 jl = qrot_inv(qb, lin), ja = qrot_inv(qb, ang);   // body-frame Jacobian column
+    const double* M = sm + LD.M + 18 * k;
+    const double* e = sm + LD.e + 6 * k;
+    const double wp = (sm + LD.wts)[2 * k], wr = (sm + LD.wts)[2 * k + 1];
+    double* o = Jw + 6 * p;
+    double cp = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      double top = M[3 * r] * jl.x + M[3 * r + 1] * jl.y + M[3 * r + 2] * jl.z + M[9 + 3 * r] * ja.x +
+                   M[9 + 3 * r + 1] * ja.y + M[9 + 3 * r + 2] * ja.z;
+      double bot = M[3 * r] * ja.x + M[3 * r + 1] * ja.y + M[3 * r + 2] * ja.z;
+      top *= wp; bot *= wr;
+      o[r] = top;
+      o[3 + r] = bot;
+      cp += top * (wp * e[r]) + bot * (wr * e[3 + r]);
+    }
+    cpart[p] = cp;   // this column's contribution to c = sum_k (W J_k)^T (W e_k)
+  }
+}
+
+// (c) lane = dof: gather c; bounds of the limited hinges (mink ConfigurationLimit)
+__device__ __forceinline__ void cvec_wide(const WideDims& D, double* sm, const char* __restrict__ img, int stage,
+                                          double limit_gain, int lane) {
+  const double* cpart = sm + LD.cpart;
+  if (lane < D.nv) {
+    const uint32_t* ci = img_at<uint32_t>(img, IM.cidx[stage]) + lane;
+    uint32_t w[WD_K / 4];
+#pragma unroll
+    for (int g = 0; g < WD_K / 4; g++) w[g] = ci[64 * g];
+    const double2 lim = img_at<double2>(img, IM.lim)[lane];
+    const uint32_t limited = img_at<uint32_t>(img, IM.limi)[lane];
+    double cc = 0.0;
+#pragma unroll
+    for (int k = 0; k < WD_K; k++) {
+      const uint32_t idx = (w[k / 4] >> (8 * (k % 4))) & 255u;
+      cc += idx != 255u ? cpart[idx] : 0.0;
+    }
+    (sm + LD.c)[lane] = cc;
+    double lo = -INFINITY, hi = INFINITY;
+    if (limited) {
+      const double th = (sm + LD.q)[7 + lane - 6];
+      hi = limit_gain * (lim.y - th);
+      lo = -limit_gain * (th - lim.x);
+    }
+    (sm + LD.lo)[lane] = lo;
+    (sm + LD.hi)[lane] = hi;
+  }
+}
+
+// (d) H: every lane sums the terms of the entries it owns (static schedule, streamed from the global image: the
+// same words for every stream of the CU) and stores each entry once, directly where the solver reads it
+struct dd2 { double x, y; };
+__device__ __forceinline__ double dot6v(const double* a, const double* b) {
+  const dd2* pa = reinterpret_cast<const dd2*>(a);
+  const dd2* pb = reinterpret_cast<const dd2*>(b);
+  dd2 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+  return (a0.x * b0.x + a0.y * b0.y + a1.x * b1.x) + (a1.y * b1.y + a2.x * b2.x + a2.y * b2.y);
+}
+
+__device__ __forceinline__ void hacc_wide(double* sm, const char* __restrict__ img, int items_off, int ntrip, double diag,
+                                          int lane) {
+  double* __restrict__ H = sm + LD.H;
+  const double* __restrict__ J = sm + LD.Jw;
+  const uint2* p = img_at<uint2>(img, items_off) + lane;
+  uint2 n[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) n[k] = p[k * 64];
+  double acc = 0.0;
+  for (int it = 0; it < ntrip; it += 4) {
+    uint2 w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = n[k];
+    if (it + 4 < ntrip) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) n[k] = p[(it + 4 + k) * 64];
+    }
+    double s[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      s[k] = dot6v(J + 6 * (w[k].x & 511u), J + 6 * ((w[k].x >> 9) & 511u));
+      if ((w[k].x >> 30) & 1u) s[k] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      acc += s[k];
+      if (w[k].y >> 31) {
+        const double v = acc + (((w[k].y >> 22) & 1u) ? diag : 0.0);
+        H[w[k].y & 2047u] = v;
+        H[(w[k].y >> 11) & 2047u] = v;
+        acc = 0.0;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// box-constrained strictly convex QP (App. A.6), tree-structured: see gmr_ik_tree.h for the algorithm.  This is its
+// one-wavefront form on the compact H: row group g = lane >> 4 eliminates limb g (rows 0..6 of the group: D_g, rows
+// 7..15: B_g and, redundantly in every group, the trunk).  Bound sets in lane coordinates: bit 16 g + a = limb
+// variable (g, a), bit 7 + t = trunk variable t (its owner is the trunk lane of group 0).
+// ---------------------------------------------------------------------------------------------
+struct RowState { unsigned long long lower, upper; };
+
+__device__ __forceinline__ int solve_rows(const WideDims& D, double* sm, const char* __restrict__ img, int lane_in,
+                                          RowState& bs, Prof& pr) {
+  constexpr int NL = WD_NL, NT = WD_NT, NV = NL + NT, TLD = WD_LD;
+  static_assert(NV == 16, "a limb's local matrix fills one 16-lane row");
+  const int grp = lane_in >> 4, lane = lane_in & 15;
+  const double* H = sm + LD.H;
+  double* xs = sm + LD.x;
+  const double* los = sm + LD.lo;
+  const double* his = sm + LD.hi;
+  double* Spart = sm + LD.spart;                  // [4][NT][NT]
+  double* rpart = sm + LD.rpart;                  // [4][NT]
+  double* xl = sm + LD.xl;                        // x by owner lane (multipliers)
+  double* Lscr = sm + LD.lscr + grp * 16 * TLD;   // this group's transpose scratch
+  unsigned long long* vset = reinterpret_cast<unsigned long long*>(sm + LD.vset);   // {to_lower, to_upper, release, flags} x 2
+  const int* tree = img_at<int>(img, IM.tree);
+
+  const bool is_limb = lane < NL, is_trunk = !is_limb;
+  const int a = lane, t = lane - NL;
+  const int dof = tree[lane_in];
+  const bool row = dof >= 0;                                  // this lane holds a real row
+  const bool own = row && (is_limb || grp == 0);              // ... and reports the variable's violations
+  const int me = is_limb ? lane_in : lane;                    // the variable's bit in the bound sets
+  const double lo = row ? los[dof] : 0.0, hi = row ? his[dof] : 0.0;
+  const double ci = row ? (sm + LD.c)[dof] : 0.0;
+  const double* LMrow = H + 7 * lane_in;                      // D_g row a (limb lanes) / B_g row t (trunk lanes)
+  const double* Trow = H + WD_HT + NT * (is_trunk ? t : 0);
+  const double cabs = lane_in < D.nv ? fabs((sm + LD.c)[lane_in]) : 0.0;
+  const double dual_tol = 1e-13 * (1.0 + rows3_max(cabs));
+  const double ptol_lo = 1e-12 * (1.0 + fabs(lo)), ptol_hi = 1e-12 * (1.0 + fabs(hi));
+  const unsigned long long absent = __ballot(!row);           // rows without a variable (short limbs / trunk)
+
+  int pcount = 3, ninf_best = 65;
+  for (int it = 0; it < 100; it++) {
+    PROF_BEGIN(pr);
+    const unsigned long long fixedm = bs.lower | bs.upper;
+    const unsigned long long gone = fixedm | absent;          // columns that are the identity in this round
+    const unsigned cf = (unsigned)(gone >> (16 * grp)) & 0x7Fu;   // limb columns of this group
+    const unsigned tf = (unsigned)(gone >> NL) & 0x1FFu;          // trunk columns (wave-uniform)
+    const bool self_fixed = !row || ((fixedm >> me) & 1ull);
+    const double xfix = !row ? 0.0 : (((bs.lower >> me) & 1ull) ? lo : (((bs.upper >> me) & 1ull) ? hi : 0.0));
+    // ---- (1) local rows and right-hand side -----------------------------------------------------
+    double r[NV];
+#pragma unroll
+    for (int m = 0; m < NV; m++) r[m] = 0.0;
+    {
+      double h[NL];
+#pragma unroll
+      for (int m = 0; m < NL; m++) h[m] = LMrow[m];
+#pragma unroll
+      for (int m = 0; m < NL; m++) {
+        const bool cfixed = (cf >> m) & 1u;
+        const bool keep = !self_fixed && !cfixed && (is_trunk || m <= a);
+        double v = keep ? h[m] : 0.0;
+        if (is_limb && m == a && (self_fixed || cfixed)) v = 1.0;   // fixed / padding limb row: identity
+        r[m] = v;
+      }
+    }
+    // -c_i - sum over fixed j of H_ij x_j (the bound value of j from the uniform sets)
+    double rhs0 = row ? (self_fixed ? xfix : -ci) : 0.0;
+    {
+      unsigned long long mm = fixedm;
+      while (mm) {
+        const int j = __ffsll((long long)mm) - 1;               // owner lane of a fixed variable (wave-uniform)
+        mm &= mm - 1;
+        const int dj = tree[j];
+        const double bj = ((bs.lower >> j) & 1ull) ? los[dj] : his[dj];
+        const int jr = j & 15, lj = j >> 4;
+        double coef;
+        if (jr < NL) coef = is_limb ? (grp == lj ? LMrow[jr] : 0.0) : H[7 * (16 * lj + lane) + jr];
+        else coef = is_limb ? H[7 * (16 * grp + jr) + a] : Trow[jr - NL];
+        if (row && !self_fixed) rhs0 -= coef * bj;
+      }
+    }
+    double b = is_limb ? rhs0 : 0.0;
+    PROF_END(pr, PH_KBUILD);
+    PROF_BEGIN(pr);
+    // ---- (2) eliminate the limb pivots (right-looking, forward substitution merged) --------------
+    double mydinv = 1.0;
+    bool bad = false;
+    double dp = row_bcast_d(r[0], 0);
+    double dinv = fast_rsqrt(dp);
+#pragma unroll
+    for (int p = 0; p < NL; p++) {
+      bad = bad || !(dp > 0.0);
+      double l = lane > p ? r[p] * dinv : 0.0;               // column p of L_g (rows > p) and of Y_g
+      if (lane == p) { mydinv = dinv; r[p] = dp * dinv; } else r[p] = l;
+      double dinv_next = 1.0;
+      if (p + 1 < NL) {
+        r[p + 1] = fma(-l, row_bcast_d(l, p + 1), r[p + 1]);
+        dp = row_bcast_d(r[p + 1], p + 1);
+        dinv_next = fast_rsqrt(dp);
+      }
+      const double yp = row_bcast_d(b, p) * dinv;
+      b = lane == p ? yp : fma(-l, yp, b);
+#pragma unroll
+      for (int k = (p + 1 < NL ? p + 2 : p + 1); k < NV; k++) r[k] = fma(-l, row_bcast_d(l, k), r[k]);
+      dinv = dinv_next;
+    }
+    PROF_END(pr, PH_CHOL);
+    PROF_BEGIN(pr);
+    // ---- (3) publish the Schur contribution; park L_g / Y_g for the transposed reads --------------
+    if (is_trunk) {
+#pragma unroll
+      for (int u = 0; u < NT; u++) Spart[(grp * NT + t) * NT + u] = r[NL + u];
+      rpart[grp * NT + t] = b;
+    }
+#pragma unroll
+    for (int m = 0; m < NL; m++) Lscr[lane * TLD + m] = r[m];
+    unsigned long long* vcur = vset + 4 * (it & 1);
+    if (lane == 0 && bad) atomicOr(&vcur[3], 1ull);
+    wsync();                                                                                 // B1
+    // the other slot was last read before this point: clear it for the next round
+    if (lane_in < 4) vset[4 * ((it + 1) & 1) + lane_in] = 0ull;
+    PROF_END(pr, PH_SUBST);
+    PROF_BEGIN(pr);
+    // ---- (4) every group: trunk Schur complement, factor, solve (redundant, no exchange) -----------
+    double bt = 0.0;
+    bool tbad = false;
+    {
+      double s[NT];
+      {
+        const int tt = is_trunk ? t : 0;
+        double hv[NT], sp[NT];
+#pragma unroll
+        for (int u = 0; u < NT; u++) {
+          hv[u] = Trow[u];
+          const double* q0 = Spart + tt * NT + u;
+          sp[u] = (q0[0] + q0[NT * NT]) + (q0[2 * NT * NT] + q0[3 * NT * NT]);
+        }
+        const double rp = (rpart[tt] + rpart[NT + tt]) + (rpart[2 * NT + tt] + rpart[3 * NT + tt]);
+        const bool live = is_trunk && row && !self_fixed;
+#pragma unroll
+        for (int u = 0; u < NT; u++) {
+          const bool cfixed = (tf >> u) & 1u;                                  // wave-uniform
+          double v = (live && !cfixed && u <= t) ? hv[u] + sp[u] : 0.0;
+          if (is_trunk && u == t && !(live && !cfixed)) v = 1.0;
+          s[u] = v;
+        }
+        bt = is_trunk ? (live ? rhs0 + rp : rhs0) : 0.0;
+      }
+      double tdinv = 1.0;
+      double dq = row_bcast_d(s[0], NL);
+      double dinv2 = fast_rsqrt(dq);
+#pragma unroll
+      for (int q = 0; q < NT; q++) {
+        tbad = tbad || !(dq > 0.0);
+        double l = t > q ? s[q] * dinv2 : 0.0;
+        if (t == q) { tdinv = dinv2; s[q] = dq * dinv2; } else s[q] = l;
+        double dinv_next = 1.0;
+        if (q + 1 < NT) {
+          s[q + 1] = fma(-l, row_bcast_d(l, NL + q + 1), s[q + 1]);
+          dq = row_bcast_d(s[q + 1], NL + q + 1);
+          dinv_next = fast_rsqrt(dq);
+        }
+        const double yq = row_bcast_d(bt, NL + q) * dinv2;
+        bt = t == q ? yq : fma(-l, yq, bt);
+#pragma unroll
+        for (int k = q + 2; k < NT; k++) s[k] = fma(-l, row_bcast_d(l, NL + k), s[k]);
+        dinv2 = dinv_next;
+      }
+      // back substitution: L^T through this group's scratch (columns 7..15 of rows 7..15)
+      double* Tscr = Lscr + NL;
+      if (is_trunk) {
+#pragma unroll
+        for (int u = 0; u < NT; u++) Tscr[lane * TLD + u] = s[u];
+      }
+      wsync();
+      double lt[NT];
+#pragma unroll
+      for (int q = 0; q < NT; q++) lt[q] = is_trunk ? Tscr[(NL + q) * TLD + t] : 0.0;
+#pragma unroll
+      for (int q = NT - 1; q >= 0; q--) {
+        const double xq = row_bcast_d(bt * tdinv, NL + q);
+        bt = t == q ? xq : (is_trunk && t < q ? fma(-lt[q], xq, bt) : bt);
+      }
+    }
+    PROF_END(pr, PH_RATIO);
+    PROF_BEGIN(pr);
+    // ---- (5) limbs: y_g - Y_g^T x_T, then back substitution with L_g^T ----------------------------
+    double x = bt;                                                                     // trunk lanes
+    {
+      double lt[NL];
+#pragma unroll
+      for (int m = 0; m < NL; m++) lt[m] = is_limb ? Lscr[m * TLD + a] : 0.0;          // column a of L_g
+      double bb = b;                                                                   // y_g (limb lanes)
+#pragma unroll
+      for (int u = 0; u < NT; u++) {
+        const double xt = row_bcast_d(bt, NL + u);
+        if (is_limb) bb = fma(-Lscr[(NL + u) * TLD + a], xt, bb);                      // Y_g[u][a]
+      }
+#pragma unroll
+      for (int p = NL - 1; p >= 0; p--) {
+        const double xp = row_bcast_d(bb * mydinv, p);
+        bb = lane == p ? xp : (lane < p ? fma(-lt[p], xp, bb) : bb);
+      }
+      if (is_limb) x = bb;
+    }
+    // ---- (6) violated bounds (free set) / multipliers (fixed set): g = H x + c ---------------------
+    if (fixedm != 0ull) {                                     // multipliers need the whole x, by owner lane
+      if (is_limb || grp == 0) xl[lane_in] = row ? x : 0.0;
+      wsync();                                                                               // B2
+    }
+    PROF_END(pr, PH_MULT);
+    PROF_BEGIN(pr);
+    int newst = 0;                                            // 0 none, 1 -> lower, 2 -> upper, 3 release
+    if (own) {
+      if (!self_fixed) {
+        if (x < lo - ptol_lo) newst = 1;
+        else if (x > hi + ptol_hi) newst = 2;
+      } else {
+        double g0 = ci, g1 = 0.0;
+        if (is_limb) {                                        // row of a limb variable: D_g[a][:] and B_g[:][a]
+#pragma unroll
+          for (int m = 0; m < NL; m++) g0 = fma(LMrow[m], xl[16 * grp + m], g0);
+#pragma unroll
+          for (int u = 0; u < NT; u++) g1 = fma(H[7 * (16 * grp + NL + u) + a], xl[NL + u], g1);
+        } else {                                              // row of a trunk variable: B_l[t][:] of every limb, T[t][:]
+#pragma unroll
+          for (int l = 0; l < 4; l++)
+#pragma unroll
+            for (int m = 0; m < NL; m++) g0 = fma(H[7 * (16 * l + lane) + m], xl[16 * l + m], g0);
+#pragma unroll
+          for (int u = 0; u < NT; u++) g1 = fma(Trow[u], xl[NL + u], g1);
+        }
+        const double g = g0 + g1;
+        const bool at_lower = (bs.lower >> me) & 1ull;
+        if (at_lower ? g < -dual_tol : g > dual_tol) newst = 3;
+      }
+    }
+    // each violating owner lane sets its variable's bit in the round's set (LDS atomic OR: order-independent)
+    if (newst != 0) atomicOr(&vcur[newst - 1], 1ull << me);
+    if (lane == 0 && tbad) atomicOr(&vcur[3], 1ull);
+    wsync();                                                                                 // B3
+    PROF_END(pr, PH_IO);
+    const unsigned long long to_lo = vcur[0], to_up = vcur[1], rel = vcur[2];
+    if (vcur[3]) return GMR_STATUS_QP_FAILED;
+    const unsigned long long all = to_lo | to_up | rel;
+    if (all == 0ull) {
+      if (own) xs[dof] = fmin(fmax(x, lo), hi);
+      wsync();
+      return GMR_STATUS_OK;
+    }
+    const int total = __popcll(all);
+    unsigned long long sel = all;                             // block principal pivoting: exchange all
+    if (total < ninf_best) { ninf_best = total; pcount = 3; }
+    else if (pcount > 0) pcount--;
+    else sel = 1ull << (63 - __clzll((long long)all));        // Murty: only the highest violated variable
+    bs.lower = (bs.lower & ~(rel & sel)) | (to_lo & sel);
+    bs.upper = (bs.upper & ~(rel & sel)) | (to_up & sel);
+  }
+  return GMR_STATUS_QP_MAXITER;
+}
+
+// (sin, cos) of every hinge's half angle for a configuration that did not come out of integrate_wide (q0)
+__device__ __forceinline__ void hinge_sincos(const WideDims& D, double* sm, int lane) {
+  if (lane >= 6 && lane < D.nv) {
+    double s, c;
+    sincos(0.5 * (sm + LD.q)[7 + lane - 6], &s, &c);
+    double* sc = sm + LD.hsc + 2 * (lane - 6);
+    sc[0] = s; sc[1] = c;
+  }
+}
+
+// mj_integratePos with v = dq/dt (App. A.7): lane 0 the free joint, lane 6+h hinge h (see integrate_wave)
+__device__ __forceinline__ void integrate_wide(const WideDims& D, double* sm, double dt, int lane, Prof& pr) {
+  PROF_BEGIN(pr);
+  double* q = sm + LD.q;
+  const double* dq = sm + LD.x;
+  const bool base = lane == 0, hinge = lane >= 6 && lane < D.nv;
+  double half = 0.0, inv = 0.0;
+  bool rotate = false;
+  if (base) {
+    q[0] += dq[0]; q[1] += dq[1]; q[2] += dq[2];
+    const double n2 = dq[3] * dq[3] + dq[4] * dq[4] + dq[5] * dq[5];
+    rotate = n2 >= 1e-30 * dt * dt;
+    if (rotate) { inv = rsqrt(n2); half = 0.5 * (n2 * inv); }
+  } else if (hinge) {
+    const double th = q[7 + lane - 6] + dq[lane];
+    q[7 + lane - 6] = th;
+    half = 0.5 * th;
+  }
+  double s, c;
+  sincos(half, &s, &c);
+  if (base) {
+    d4 quat = qnormalize(d4{q[3], q[4], q[5], q[6]});
+    if (rotate) quat = qmul(quat, d4{c, dq[3] * inv * s, dq[4] * inv * s, dq[5] * inv * s});
+    q[3] = quat.w; q[4] = quat.x; q[5] = quat.y; q[6] = quat.z;
+  } else if (hinge) {
+    double* sc = sm + LD.hsc + 2 * (lane - 6);
+    sc[0] = s; sc[1] = c;
+  }
+  wsync();
+  PROF_END(pr, PH_INTEG);
+}
+
+// target preprocessing (motion_retarget.py:203-270); lane = human body
+__device__ __forceinline__ void preprocess_wide(const WideDims& D, double* sm, const char* __restrict__ img, int human_root,
+                                                double ground_offset, int flags, int lane, Prof& pr) {
+  PROF_BEGIN(pr);
+  const double* raw = sm + LD.raw;
+  double* tgt = sm + LD.tgt;
+  double z = INFINITY;
+  d3 p = {0, 0, 0};
+  d4 uq = {1, 0, 0, 0};
+  const bool on = lane < D.nhum;
+  if (on) {
+    const double* cst = img_at<double>(img, IM.pre) + 8 * lane;
+    const double* in = raw + 7 * lane;
+    const double* rp = raw + 7 * human_root;
+    const double sr = (img_at<double>(img, IM.pre) + 8 * human_root)[0];
+    d3 srp = {sr * rp[0], sr * rp[1], sr * rp[2]};
+    if (lane == human_root) p = srp;
+    else {
+      const double s = cst[0];
+      p = d3{(in[0] - rp[0]) * s + srp.x, (in[1] - rp[1]) * s + srp.y, (in[2] - rp[2]) * s + srp.z};
+    }
+    d4 q = qnormalize(d4{in[3], in[4], in[5], in[6]});
+    uq = qnormalize(qmul(q, qnormalize(d4{cst[4], cst[5], cst[6], cst[7]})));
+    p = p + qrot(uq, d3{cst[1], cst[2], cst[3]});
+    if (img_at<uint32_t>(img, IM.prei)[lane] && p.x == p.x) z = p.z;
+  }
+  if (flags & GMR_FLAG_OFFSET_TO_GROUND) {
+    double lowest = row0_min(z);
+    p.z = p.z - lowest + ground_offset;
+  }
+  if (on) {
+    double* o = tgt + 7 * lane;
+    o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = uq.w; o[4] = uq.x; o[5] = uq.y; o[6] = uq.z;
+  }
+  wsync();
+  PROF_END(pr, PH_PRE);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(
+    const char* __restrict__ img, WideDims D, int max_iter, int human_root, int use0, int use1, int S, int T,
+    const double* __restrict__ q0, const double* __restrict__ human, const int32_t* __restrict__ len, int flags,
+    double* __restrict__ q_out, int32_t* __restrict__ nsolve, int32_t* __restrict__ status, double* __restrict__ tgt_out,
+    double* __restrict__ err_out, unsigned long long* __restrict__ prof_out) {
+  extern __shared__ __align__(16) double sm[];
+  const int lane = threadIdx.x;
+  const int s = blockIdx.x;
+  if (s >= S) return;
+  Prof pr;
+#ifdef GMR_IK_PROFILE
+  for (int i = 0; i < PH_COUNT; i++) pr.acc[i] = 0;
+  const unsigned long long k_t0 = __builtin_amdgcn_s_memtime(), k_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  const int nq = D.nq, nhum = D.nhum;
+  const double* prm = img_at<double>(img, IM.prm);   // damping, lm_damping, tol, limit_gain, ground_offset, dt
+  // state that must start defined: the violation sets of the QP (double-buffered, cleared round by round)
+  if (lane < 8) reinterpret_cast<unsigned long long*>(sm + LD.vset)[lane] = 0ull;
+  for (int i = lane; i < nq; i += 64) (sm + LD.q)[i] = q0[(size_t)s * nq + i];
+  wsync();
+  hinge_sincos(D, sm, lane);
+  wsync();
+  fk_wide(D, sm, img, lane, pr);
+
+  const int Ts = len ? min(len[s], T) : T;
+  const size_t fstride = (size_t)nhum * 7;
+  const double* hs = human + (size_t)s * T * fstride;
+  int stat = GMR_STATUS_OK;
+  RowState bounds = {0ull, 0ull};
+  int h_stage = -1;     // stage whose sparsity pattern H currently holds
+  double r0 = 0.0, r1 = 0.0;
+  if (Ts > 0) {
+    if (lane < (int)fstride) r0 = hs[lane];
+    if (lane + 64 < (int)fstride) r1 = hs[lane + 64];
+  }
+  for (int t = 0; t < Ts; t++) {
+    if (lane < (int)fstride) (sm + LD.raw)[lane] = r0;
+    if (lane + 64 < (int)fstride) (sm + LD.raw)[lane + 64] = r1;
+    if (t + 1 < Ts) {                                  // prefetch the next frame (nhuman * 7 <= 112 doubles)
+      const double* nx = hs + (size_t)(t + 1) * fstride;
+      if (lane < (int)fstride) r0 = nx[lane];
+      if (lane + 64 < (int)fstride) r1 = nx[lane + 64];
+    }
+    wsync();
+    int ns0 = 0, ns1 = 0;
+    const size_t f = (size_t)s * T + t;
+    if (stat == GMR_STATUS_OK) {
+      preprocess_wide(D, sm, img, human_root, prm[4], flags, lane, pr);
+      if (tgt_out)     // the poses handed to task.set_target (motion_retarget.py:117-136) = scaled_human_data
+        for (int i = lane; i < (int)fstride; i += 64) tgt_out[f * fstride + i] = (sm + LD.tgt)[i];
+      for (int stage = 0; stage < 2; stage++) {
+        if (!(stage == 0 ? use0 : use1) || (flags & GMR_FLAG_EVAL_ONLY)) continue;
+        const int K = D.K[stage];
+        const uint32_t taskw = lane < K ? img_at<uint32_t>(img, IM.taski[stage])[lane] : 0u;
+        if (h_stage != stage) {
+          // structural zeros of the compact H are never written by the schedule: clear when the pattern changes
+          for (int i = lane; i < WD_HN; i += 64) (sm + LD.H)[i] = 0.0;
+          h_stage = stage;
+          wsync();
+        }
+        double curr = errors_wide(sm, taskw, K, lane, pr);
+        int nsol = 0, num_iter = 0;
+        for (;;) {
+          const double mu = jlog_wide(sm, img, stage, K, prm[1], lane, pr);
+          const double diag = prm[0] + mu;
+          PROF_BEGIN(pr);
+          pairs_wide(sm, img, stage, D.P[stage], lane);
+          wsync();
+          PROF_END(pr, PH_PAIRS);
+          PROF_BEGIN(pr);
+          cvec_wide(D, sm, img, stage, prm[3], lane);
+          PROF_END(pr, PH_CVEC);
+          PROF_BEGIN(pr);
+          hacc_wide(sm, img, D.items[stage], D.ntrip[stage], diag, lane);
+          wsync();
+          PROF_END(pr, PH_HACC);
+          PROF_COUNT(pr, PH_NSOLVE);
+          PROF_COUNT(pr, PH_NFACT);
+          const int rc = solve_rows(D, sm, img, lane, bounds, pr);
+          if (rc != GMR_STATUS_OK) { stat = rc; break; }
+          integrate_wide(D, sm, prm[5], lane, pr);
+          fk_wide(D, sm, img, lane, pr);
+          const double next = errors_wide(sm, taskw, K, lane, pr);
+          nsol++;
+          if (nsol > 1) num_iter++;
+          if (!(curr - next > prm[2] && num_iter < max_iter)) break;
+          curr = next;
+        }
+        if (stage == 0) ns0 = nsol; else ns1 = nsol;
+        if (stat != GMR_STATUS_OK) break;
+      }
+    }
+    if (err_out && stat == GMR_STATUS_OK) {
+      // error1() / error2() of the reference (motion_retarget.py:188-200) at the configuration this frame ends with
+      for (int stage = 0; stage < 2; stage++) {
+        double E = 0.0;
+        if (stage == 0 ? use0 : use1) {
+          const int K = D.K[stage];
+          E = errors_wide(sm, lane < K ? img_at<uint32_t>(img, IM.taski[stage])[lane] : 0u, K, lane, pr);
+        }
+        if (lane == 0) err_out[2 * f + stage] = E;
+      }
+    }
+    for (int i = lane; i < nq; i += 64) q_out[f * nq + i] = (sm + LD.q)[i];
+    if (lane == 0) { nsolve[2 * f] = ns0; nsolve[2 * f + 1] = ns1; }
+    wsync();
+  }
+  if (lane == 0) status[s] = stat;
+#ifdef GMR_IK_PROFILE
+  pr.acc[PH_TICKS] = __builtin_amdgcn_s_memtime() - k_t0;
+  pr.acc[PH_REALTIME] = __builtin_amdgcn_s_memrealtime() - k_r0;
+  if (lane == 0 && prof_out)
+    for (int i = 0; i < PH_COUNT; i++) prof_out[(size_t)s * PH_COUNT + i] = pr.acc[i];
+#else
+  (void)prof_out;
+#endif
+}
+
+}  // namespace wide
+}  // namespace gmr
+
+// host-side launcher used by gmr_abi.hip
+extern "C" hipError_t gmr_launch_ik_wide(const char* d_image, const gmr::WideLayout* L, const gmr::IkParams* P, int S, int T,
+                                         const double* d_q0, const double* d_human, const int32_t* d_len, int flags,
+                                         double* d_q_out, int32_t* d_nsolve, int32_t* d_status, double* d_tgt_out,
+                                         double* d_err_out, hipStream_t stream, unsigned long long* d_prof) {
+  if (S <= 0 || T <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gmr::wide::ik_wide_kernel, dim3(S), dim3(64), gmr::WD_LDS_BYTES, stream, d_image,
+                     static_cast<const gmr::WideDims&>(*L), P->max_iter, P->human_root, P->use0, P->use1, S, T, d_q0, d_human,
+                     d_len, flags, d_q_out, d_nsolve, d_status, d_tgt_out, d_err_out, d_prof);
+  return hipGetLastError();
+}
+
+// the kernel's registers / LDS as the runtime sees them (occupancy reporting)
+extern "C" hipError_t gmr_ik_wide_attributes(int* num_regs, int* lds_bytes, int* max_waves_per_cu) {
+  hipFuncAttributes a;
+  hipError_t e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(gmr::wide::ik_wide_kernel));
+  if (e != hipSuccess) return e;
+  if (num_regs) *num_regs = a.numRegs;
+  if (lds_bytes) *lds_bytes = gmr::WD_LDS_BYTES;
+  int nblk = 0;
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(gmr::wide::ik_wide_kernel), 64,
+                                                   gmr::WD_LDS_BYTES);
+  if (max_waves_per_cu) *max_waves_per_cu = nblk;
+  return e;
+}

@@ -1,0 +1,300 @@
+// gmr_ik_wide_layout.h -- the THROUGHPUT shape of the IK kernel (gmr_ik_wide.hip): one wavefront per stream with
+// a per-stream LDS footprint small enough for two resident wavefronts per SIMD.
+//
+// Compared with the layout of gmr_ik_layout.h (latency shape, dense fallback):
+//   * nothing that is the same for every stream lives in LDS: the robot's constants, the task tables, the tree
+//     tables and the H schedule stay in ONE global image (this header builds it) and are read with coalesced
+//     per-lane loads (vector L1 / L2 hits, shared by all streams of a CU) or scalar loads;
+//   * H is stored in the block-arrowhead form the tree solver consumes (four 16 x 7 limb matrices [D_l; B_l] and
+//     the 9 x 9 trunk block: 529 instead of 36 x 37 doubles), written there directly by the assembly schedule;
+//   * the assembly scratch and the solver scratch are trimmed and share one region.
+// 22.1 KB per stream instead of 37.5 KB: 7 instead of 4 streams per CU.
+//
+// Only robots that decompose into <= 4 limbs of <= 7 dofs and a trunk of <= 9 (every shipped robot) and fit the
+// capacities below use this shape; others keep the one-wavefront kernel of gmr_ik.hip with the dense solver.
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "gmr_ik_layout.h"
+
+namespace gmr {
+
+// capacities (one class: every shipped robot fits)
+constexpr int WD_NB = 40;        // bodies
+constexpr int WD_NH = 30;        // hinges (nv <= 36)
+constexpr int WD_K = 16;         // tasks per stage
+constexpr int WD_P = 160;        // (task, dof) pairs per stage
+constexpr int WD_NHUM = 16;      // human bodies
+constexpr int WD_NL = 7, WD_NT = 9;          // limb / trunk rows of the tree solver
+constexpr int WD_LD = 17;                    // row stride of the solver's transpose scratch (odd)
+
+// ---- LDS (offsets in doubles) ---------------------------------------------------------------------------------
+struct WideLds {
+  int q, hsc, xa, xaxis, tgt;                 // state
+  int e, wts, M, Jw, cpart, eaux, raw, xb;    // assembly scratch (eaux aliases cpart, raw aliases M, xb aliases Jw)
+  int lscr, spart, rpart, xl;                 // solver scratch (aliases the assembly scratch)
+  int H;                                      // compact H: LM[4][16][7] then T[9][9]
+  int c, x, lo, hi;
+  int vset;                                   // 8 x u64: violation sets of the pivoting rounds (double-buffered)
+  int n_double;
+};
+constexpr int WD_HT = 4 * 16 * 7;             // offset of T inside the compact H
+constexpr int WD_HN = WD_HT + WD_NT * WD_NT;  // 529 doubles
+
+constexpr WideLds wide_lds() {
+  WideLds L{};
+  int o = 0;
+  L.q = o; o += 7 + WD_NH + 1;
+  L.hsc = o; o += 2 * WD_NH;
+  L.xa = o; o += 7 * WD_NB + 1;
+  L.xaxis = o; o += 3 * WD_NB;
+  L.tgt = o; o += 7 * WD_NHUM + 1;
+  if (o & 1) o++;
+  const int s0 = o;
+  L.e = o; o += 6 * WD_K;
+  L.wts = o; o += 2 * WD_K;
+  L.M = o; o += 18 * WD_K;
+  L.raw = L.M;                                // consumed by the preprocess step, before any solve
+  if (o & 1) o++;                             // Jw rows (48 B) are read as three 16-B pieces
+  L.Jw = o; o += 6 * WD_P;
+  L.xb = L.Jw;                                // FK runs between solves, when the assembly scratch is dead
+  L.cpart = o; o += WD_P;
+  L.eaux = L.cpart;                           // (a, sin, cos) of the residual phase die before the columns are written
+  const int s1 = o;
+  // solver scratch in the same region (live only inside a solve)
+  int t = s0;
+  L.lscr = t; t += 4 * 16 * WD_LD;
+  L.spart = t; t += 4 * WD_NT * WD_NT;
+  L.rpart = t; t += 4 * WD_NT;
+  L.xl = t; t += 64;
+  o = ik_max(s1, t);
+  if (o & 1) o++;
+  L.H = o; o += WD_HN + 1;
+  L.c = o; o += 36; L.x = o; o += 36; L.lo = o; o += 36; L.hi = o; o += 36;
+  L.vset = o; o += 8;
+  L.n_double = o;
+  return L;
+}
+constexpr int WD_LDS_BYTES = wide_lds().n_double * 8;
+static_assert(7 * 18 <= 6 * WD_P && 7 * WD_NB + 1 <= 6 * WD_P, "aliases must fit");
+static_assert(7 * WD_NHUM + 1 <= 18 * WD_K, "raw frame must fit the M region");
+
+// ---- global image (offsets in bytes; every section 16-byte aligned) ----------------------------------------------
+// per-lane sections are indexed by the lane that consumes them, so that a phase starts with a few coalesced loads
+struct WideImg {
+  int fkc;        // f64 [WD_NB][10]    body_pos(3) body_quat(4) hinge axis(3)                  lane = body
+  int fki;        // u32 [WD_NB][2]     {hop round r in bits [6r+5:6r], r < 5} {depth | (hinge+1) << 8}
+  int pre;        // f64 [WD_NHUM][8]   scale, pos_off(3), quat_off(4)                         lane = human body
+  int prei;       // u32 [WD_NHUM]      is_foot
+  int task[2];    // f64 [WD_K][2] w_pos, w_rot ; then u32 [WD_K] body | human << 8              lane = task
+  int taski[2];
+  int pair[2];    // u32 [WD_P]         task | dof << 4 | task body << 10 | hinge body << 16   virtual lane = pair
+  int cidx[2];    // u8  [WD_K][64]     pair id of (task k, dof = lane) or 255, as u32 [WD_K/4][64]
+  int lim;        // f64 [64][2] range lo, hi ; then u32 [64] limited                             lane = dof
+  int limi;
+  int tree;       // i32 [64] dof of solver lane (16 l + row) or -1
+  int prm;        // f64 [8]  damping, lm_damping, tol, limit_gain, ground_offset, dt (scalar loads where used)
+  int items[2];   // u64 [ntrip][64]   (runtime size: last)
+  int fixed_bytes;
+};
+constexpr int wd_up16(int x) { return (x + 15) / 16 * 16; }
+constexpr WideImg wide_img() {
+  WideImg I{};
+  int o = 0;
+  I.fkc = o; o += wd_up16(WD_NB * 10 * 8);
+  I.fki = o; o += wd_up16(WD_NB * 2 * 4);
+  I.pre = o; o += wd_up16(WD_NHUM * 8 * 8);
+  I.prei = o; o += wd_up16(WD_NHUM * 4);
+  for (int s = 0; s < 2; s++) {
+    I.task[s] = o; o += wd_up16(WD_K * 2 * 8);
+    I.taski[s] = o; o += wd_up16(WD_K * 4);
+    I.pair[s] = o; o += wd_up16(WD_P * 4);
+    I.cidx[s] = o; o += wd_up16(WD_K * 64);
+  }
+  I.lim = o; o += wd_up16(64 * 2 * 8);
+  I.limi = o; o += wd_up16(64 * 4);
+  I.tree = o; o += wd_up16(64 * 4);
+  I.prm = o; o += 64;
+  I.fixed_bytes = o;
+  return I;
+}
+
+// what varies per robot: passed by value to the kernel
+struct WideDims {
+  int nb, nq, nv, nhum, nhop;
+  int K[2], P[2], ntrip[2];
+  int items[2];                   // byte offsets of the schedules in the image
+};
+
+struct WideLayout : WideDims {
+  int ok;                         // the robot / task set fits this shape
+  int image_bytes;
+};
+
+// H-assembly item (64 bit).  lo: [8:0] pair a, [17:9] pair b, [30] contributes nothing.
+// hi: [10:0] first store offset in the compact H (doubles), [21:11] second store offset (the symmetric twin, or the
+// same), [22] diagonal entry (the damping term is added), [31] last term of the entry.
+constexpr uint32_t WD_ITEM_NOP = 1u << 30;
+
+// position of a dof in the tree decomposition
+struct WideLoc { int limb, idx; };            // limb = -1: trunk row idx
+
+inline bool wide_fits(const gmr_model_t& m, const gmr_taskset_t& ts) {
+  const IkTree tree = make_ik_tree(m);
+  if (!tree.ok || tree.nt > WD_NT) return false;
+  for (auto& l : tree.limb) { int n = 0; for (int d : l) n += d >= 0; if (n > WD_NL) return false; }
+  if (m.nbody > WD_NB || m.nhinge > WD_NH || ts.nhuman > WD_NHUM) return false;
+  for (int s = 0; s < 2; s++) if (ts.ntask[s] > WD_K || ts.npair[s] > WD_P || ts.npair[s] > 254) return false;
+  int maxd = 1;
+  for (int b = 0; b < m.nbody; b++) maxd = std::max(maxd, m.depth[b] + 1);
+  return maxd <= 32;
+}
+
+// Static schedule of H = sum_k (W J_k)^T (W J_k) (see gmr_ik_layout.h) with the destinations expressed in the
+// compact layout: every (i >= j) entry is owned by one lane (longest-processing-time assignment) which sums its
+// terms in a fixed order and stores the entry once (twice for a symmetric twin).
+inline bool make_wide_schedule(const gmr_model_t& m, const gmr_taskset_t& ts, std::vector<uint64_t> out[2], int ntrip[2]) {
+  const int nv = m.nv;
+  const IkTree tree = make_ik_tree(m);
+  std::vector<WideLoc> loc(nv, WideLoc{-2, -1});
+  for (int l = 0; l < 4; l++) for (int a = 0; a < 8; a++) if (tree.limb[l][a] >= 0) loc[tree.limb[l][a]] = {l, a};
+  for (int t = 0; t < 10; t++) if (tree.trunk[t] >= 0) loc[tree.trunk[t]] = {-1, t};
+  for (int s = 0; s < 2; s++) {
+    std::vector<std::vector<uint32_t>> terms((size_t)nv * nv);
+    for (int k = 0; k < ts.ntask[s]; k++) {
+      int c0 = ts.task_col0[s][k], n = ts.task_ncol[s][k];
+      for (int a = 0; a < n; a++)
+        for (int b = 0; b <= a; b++) {
+          int da = ts.pair_dof[s][c0 + a], db = ts.pair_dof[s][c0 + b];
+          terms[(size_t)da * nv + db].push_back((uint32_t)(c0 + a) | ((uint32_t)(c0 + b) << 9));
+        }
+    }
+    struct Ent { int da, db, w; uint32_t hi; };
+    std::vector<Ent> ents;
+    for (int da = 0; da < nv; da++)
+      for (int db = 0; db <= da; db++) {
+        int w = (int)terms[(size_t)da * nv + db].size();
+        if (w == 0 && da != db) continue;
+        const WideLoc A = loc[da], B = loc[db];
+        int o1, o2;
+        if (A.limb >= 0 && B.limb >= 0) {
+          if (A.limb != B.limb) return false;                    // two limbs never share a task path
+          o1 = (16 * A.limb + A.idx) * 7 + B.idx; o2 = (16 * A.limb + B.idx) * 7 + A.idx;
+        } else if (A.limb >= 0) { o1 = o2 = (16 * A.limb + 7 + B.idx) * 7 + A.idx; }
+        else if (B.limb >= 0) { o1 = o2 = (16 * B.limb + 7 + A.idx) * 7 + B.idx; }
+        else { o1 = WD_HT + A.idx * WD_NT + B.idx; o2 = WD_HT + B.idx * WD_NT + A.idx; }
+        ents.push_back({da, db, w, (uint32_t)o1 | ((uint32_t)o2 << 11) | (da == db ? 1u << 22 : 0u)});
+      }
+    std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.w > y.w; });
+    std::vector<std::vector<Ent>> per_lane(64);
+    std::vector<int> load(64, 0);
+    for (const Ent& e : ents) {
+      int best = 0;
+      for (int l = 1; l < 64; l++) if (load[l] < load[best]) best = l;
+      per_lane[best].push_back(e);
+      load[best] += std::max(e.w, 1) + 1;
+    }
+    int nt = 0;
+    std::vector<std::vector<uint64_t>> li(64);
+    for (int l = 0; l < 64; l++) {
+      for (const Ent& e : per_lane[l]) {
+        const auto& tt = terms[(size_t)e.da * nv + e.db];
+        if (tt.empty()) li[l].push_back(((uint64_t)(e.hi | (1u << 31)) << 32) | WD_ITEM_NOP);
+        for (size_t i = 0; i < tt.size(); i++)
+          li[l].push_back(((uint64_t)(e.hi | (i + 1 == tt.size() ? (1u << 31) : 0u)) << 32) | tt[i]);
+      }
+      nt = std::max(nt, (int)li[l].size());
+    }
+    nt = (nt + 3) & ~3;                                           // four slots per loop trip
+    ntrip[s] = nt;
+    out[s].assign((size_t)nt * 64, (uint64_t)WD_ITEM_NOP);
+    for (int l = 0; l < 64; l++)
+      for (size_t i = 0; i < li[l].size(); i++) out[s][i * 64 + l] = li[l][i];
+  }
+  return true;
+}
+
+inline WideLayout make_wide_layout(const gmr_model_t& m, const gmr_taskset_t& ts, std::vector<char>* image) {
+  WideLayout L{};
+  L.ok = 0;
+  if (!wide_fits(m, ts)) return L;
+  std::vector<uint64_t> items[2];
+  if (!make_wide_schedule(m, ts, items, L.ntrip)) return L;
+  constexpr WideImg I = wide_img();
+  L.nb = m.nbody; L.nq = m.nq; L.nv = m.nv; L.nhum = ts.nhuman;
+  int maxd = 1;
+  for (int b = 0; b < m.nbody; b++) maxd = std::max(maxd, m.depth[b] + 1);
+  L.nhop = 0;
+  while ((1 << L.nhop) < maxd) L.nhop++;
+  int o = I.fixed_bytes;
+  for (int s = 0; s < 2; s++) { L.K[s] = ts.ntask[s]; L.P[s] = ts.npair[s]; L.items[s] = o; o += wd_up16((int)items[s].size() * 8); }
+  L.image_bytes = o;
+  L.ok = 1;
+  if (!image) return L;
+  image->assign((size_t)o, 0);
+  char* base = image->data();
+  auto F = [&](int off) { return reinterpret_cast<double*>(base + off); };
+  auto U = [&](int off) { return reinterpret_cast<uint32_t*>(base + off); };
+  for (int b = 0; b < m.nbody; b++) {
+    double* d = F(I.fkc) + 10 * b;
+    for (int a = 0; a < 3; a++) d[a] = m.body_pos[b][a];
+    for (int a = 0; a < 4; a++) d[3 + a] = m.body_quat[b][a];
+    const int h = m.body_hinge[b];
+    for (int a = 0; a < 3; a++) d[7 + a] = h >= 0 ? m.hinge_axis[h][a] : 0.0;
+    const int dep = m.depth[b];
+    uint32_t hops = 0;
+    for (int r = 0; r < L.nhop; r++) hops |= (uint32_t)(dep >= (1 << r) ? m.chain[b][dep - (1 << r)] : 0) << (6 * r);
+    U(I.fki)[2 * b] = hops;
+    U(I.fki)[2 * b + 1] = (uint32_t)dep | ((uint32_t)(h + 1) << 8);
+  }
+  for (int i = 0; i < ts.nhuman; i++) {
+    double* d = F(I.pre) + 8 * i;
+    d[0] = ts.scale[i];
+    for (int a = 0; a < 3; a++) d[1 + a] = ts.pos_off[i][a];
+    for (int a = 0; a < 4; a++) d[4 + a] = ts.quat_off[i][a];
+    U(I.prei)[i] = (uint32_t)ts.is_foot[i];
+  }
+  for (int s = 0; s < 2; s++) {
+    for (int k = 0; k < ts.ntask[s]; k++) {
+      F(I.task[s])[2 * k] = ts.w_pos[s][k];
+      F(I.task[s])[2 * k + 1] = ts.w_rot[s][k];
+      U(I.taski[s])[k] = (uint32_t)ts.task_body[s][k] | ((uint32_t)ts.task_human[s][k] << 8);
+    }
+    for (int p = 0; p < ts.npair[s]; p++) {
+      const int k = ts.pair_task[s][p], d = ts.pair_dof[s][p];
+      U(I.pair[s])[p] = (uint32_t)k | ((uint32_t)d << 4) | ((uint32_t)ts.task_body[s][k] << 10) |
+                        ((uint32_t)(d >= 6 ? m.hinge_body[d - 6] : 0) << 16);
+    }
+    uint8_t* ci = reinterpret_cast<uint8_t*>(base + I.cidx[s]);       // [k / 4][lane][k % 4]
+    for (int k = 0; k < WD_K; k++)
+      for (int d = 0; d < 64; d++) {
+        int v = (k < ts.ntask[s] && d < m.nv) ? ts.pair_index[s][k][d] : -1;
+        ci[((k / 4) * 64 + d) * 4 + (k % 4)] = (uint8_t)(v >= 0 ? v : 255);
+      }
+    std::memcpy(base + L.items[s], items[s].data(), items[s].size() * 8);
+  }
+  for (int d = 0; d < 64; d++) {
+    const int h = d - 6;
+    const bool lim = h >= 0 && h < m.nhinge && m.limited[h];
+    F(I.lim)[2 * d] = lim ? m.range_lo[h] : 0.0;
+    F(I.lim)[2 * d + 1] = lim ? m.range_hi[h] : 0.0;
+    U(I.limi)[d] = lim ? 1u : 0u;
+  }
+  {
+    const double prm[6] = {ts.damping, ts.lm_damping, ts.tol, ts.limit_gain, ts.ground_offset, m.timestep};
+    for (int i = 0; i < 6; i++) F(I.prm)[i] = prm[i];
+  }
+  {
+    const IkTree tree = make_ik_tree(m);
+    int32_t* td = reinterpret_cast<int32_t*>(base + I.tree);
+    for (int l = 0; l < 4; l++)
+      for (int r = 0; r < 16; r++) td[16 * l + r] = r < WD_NL ? tree.limb[l][r] : tree.trunk[r - WD_NL];
+  }
+  return L;
+}
+
+}  // namespace gmr

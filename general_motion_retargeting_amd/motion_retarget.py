@@ -7,10 +7,10 @@ Mirrors reference ``general_motion_retargeting/motion_retarget.py``:
 * ``__init__``                      :13-72   (same signature, same public attributes)
 * ``update_targets`` / ``retarget`` :117-185 (same in-place ``to_numpy`` mutation of the caller's
   dict, same ``KeyError`` behaviour, returns a fresh float64 ``qpos`` copy)
+* ``scaled_human_data``, ``error1`` / ``error2`` :118-124, :188-200 -- served from what the kernel computed for the
+  last frame (its ``tgt_out`` / ``err_out``); after ``update_targets()`` alone, from a solve-free launch
 * ``scale_human_data`` / ``offset_human_data`` / ``offset_human_data_to_ground`` / ``to_numpy``
-  :203-270 (NumPy, used for ``scaled_human_data``; the IK itself consumes the raw packed frame and
-  preprocesses on the device)
-* ``error1`` / ``error2``           :188-200
+  :203-270 (NumPy helpers kept for callers; the retargeting path preprocesses on the device)
 
 plus the batched entry points that the per-frame API cannot express (``retarget_clip``,
 ``retarget_streams``): many frames / many independent streams per launch, time loop on device.
@@ -25,7 +25,6 @@ from . import _lib
 from .ik_config import TaskTables, build_task_tables, pack_model, pack_taskset
 from .models import load_ik_config, load_robot
 from .params import IK_CONFIG_DICT, ROBOT_XML_DICT
-from .synth import fk_numpy, quat_conj, quat_mul, quat_rotate
 
 
 class TargetNotSet(Exception):
@@ -53,29 +52,16 @@ class _Configuration:
             self.data.qpos = np.asarray(q, dtype=np.float64).copy()
 
 
-def _so3_log(q):
-    w = q[0]
-    n2 = float(q[1:] @ q[1:])
-    if n2 < 1e-10:
-        f = 2.0 / w - 2.0 / 3.0 * n2 / w ** 3
-    else:
-        n = np.sqrt(n2)
-        f = (1.0 if w > 0 else -1.0) * np.pi / n if abs(w) < 1e-10 else 2.0 * np.arctan2(-n if w < 0 else n, abs(w)) / n
-    return f * q[1:]
+def _quat_mul(a, b):
+    w1, x1, y1, z1 = a
+    w2, x2, y2, z2 = b
+    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                     w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
 
 
-def _se3_log_rel(pb, qb, pt, qt):
-    qbt = quat_mul(quat_conj(qb), qt)
-    pbt = quat_rotate(quat_conj(qb), pt - pb)
-    w = _so3_log(qbt)
-    t2 = float(w @ w)
-    if t2 < 1e-2:
-        a = 1 / 12 + t2 * (1 / 720 + t2 * (1 / 30240 + t2 * (1 / 1209600 + t2 / 47900160)))
-    else:
-        t = np.sqrt(t2)
-        a = (1.0 - 0.5 * t * np.cos(0.5 * t) / np.sin(0.5 * t)) / t2
-    wp = np.cross(w, pbt)
-    return np.concatenate([pbt - 0.5 * wp + a * np.cross(w, wp), w])
+def _quat_rotate(q, v):
+    qv = np.concatenate([[0.0], v])
+    return _quat_mul(_quat_mul(q, qv), q * np.array([1.0, -1.0, -1.0, -1.0]))[1:]
 
 
 class GeneralMotionRetargeting:
@@ -116,7 +102,7 @@ class GeneralMotionRetargeting:
         self.damping = damping
         self.pos_offsets1 = {k: v.copy() for k, v in tt.pos_offsets1.items()}
         self.rot_offsets1 = {k: v.copy() for k, v in tt.rot_offsets1.items()}   # wxyz, normalised
-        self._scaled_src = None
+        self._raw_frame = None
         self._scaled_cache = None
 
         self._human_names: List[str] = tt.human_names
@@ -181,39 +167,75 @@ class GeneralMotionRetargeting:
     # ------------------------------------------------------------------ #
     def update_targets(self, human_data, offset_to_ground=False):
         human_data = self.to_numpy(human_data)
-        self._raw_frame = self.pack_frame(human_data)
-        # the reference computes scaled_human_data eagerly (:118-124); only viewers read it, so it is
-        # derived on first access here (the IK consumes the raw packed frame and preprocesses on device)
-        self._scaled_src = (human_data, bool(offset_to_ground))
+        self._set_frame(self.pack_frame(human_data), offset_to_ground, list(human_data.keys()))
+
+    def _set_frame(self, frame, offset_to_ground, key_order=None):
+        """New targets (a packed frame): everything derived from the previous ones is stale."""
+        self._raw_frame = frame
+        self._ground_flag = bool(offset_to_ground)
+        self._key_order = key_order
+        self._targets = None          # f64[nhuman, 7]: the kernel's preprocessed frame (tgt_out)
+        self._errors = None           # (error1, error2) at self._errors_q
+        self._errors_q = None
+        self._scaled_cache = None
+
+    def _flags(self, offset_to_ground):
+        return _lib.FLAG_OFFSET_TO_GROUND if offset_to_ground else 0
+
+    def _evaluate(self):
+        """Targets and residual norms of the current (frame, configuration) WITHOUT a solve: the device runs the
+        preprocessing and both tables' residuals (GMR_FLAG_EVAL_ONLY) -- update_targets() followed by
+        scaled_human_data / error1() / error2() in the reference (:117-136, :188-200)."""
+        if getattr(self, "_raw_frame", None) is None:
+            raise TargetNotSet("retarget()/update_targets() has not been called")
+        q = self.configuration.data.qpos
+        _, _, status, tg, er = self.hip_solver.retarget_streams(
+            q[None], self._raw_frame[None, None], flags=self._flags(self._ground_flag) | _lib.FLAG_EVAL_ONLY,
+            want_targets=True, want_errors=True)
+        if status[0] != 0:
+            raise RuntimeError(f"evaluation failed (status {int(status[0])})")
+        self._targets, self._errors, self._errors_q = tg[0, 0], er[0, 0], q.copy()
         self._scaled_cache = None
 
     @property
     def scaled_human_data(self):
-        if self._scaled_cache is None and self._scaled_src is not None:
-            human_data, ground = self._scaled_src
-            hd = self.scale_human_data(human_data, self.human_root_name, self.human_scale_table)
-            hd = self.offset_human_data(hd, self.pos_offsets1, self.rot_offsets1)
-            if ground:
-                hd = self.offset_human_data_to_ground(hd)
-            self._scaled_cache = hd
+        """``{name: [pos, quat_wxyz]}`` after scale / offset / ground (reference :118-124), exactly the values the
+        IK kernel computed for the last frame (its ``tgt_out``), in the reference's dict order."""
+        if self._scaled_cache is None:
+            if getattr(self, "_raw_frame", None) is None:
+                return None
+            if self._targets is None:
+                self._evaluate()
+            names = self._human_names
+            rows = {n: self._targets[i] for i, n in enumerate(names) if not np.isnan(self._raw_frame[i, 0])}
+            order = [self.human_root_name] + [n for n in (self._key_order or names) if n != self.human_root_name]
+            self._scaled_cache = {n: [rows[n][:3].copy(), rows[n][3:].copy()] for n in order if n in rows}
         return self._scaled_cache
 
     @scaled_human_data.setter
     def scaled_human_data(self, value):
         self._scaled_cache = value
-        self._scaled_src = None
+
+    def _run(self, human, offset_to_ground, key_order=None):
+        """One launch over ``human[T, nhuman, 7]`` continuing from the current configuration; keeps the last
+        frame's targets and residual norms so that scaled_human_data / error1() / error2() refer to it."""
+        q_out, nsolve, status, tg, er = self.hip_solver.retarget_streams(
+            self.configuration.data.qpos[None], human[None], flags=self._flags(offset_to_ground),
+            want_targets=True, want_errors=True)
+        if status[0] != 0:
+            raise RuntimeError(f"IK failed (status {int(status[0])}): QP not solvable / non-finite input")
+        self._set_frame(human[-1], offset_to_ground, key_order)
+        self.configuration.data.qpos = q_out[0, -1].copy()
+        self._targets, self._errors, self._errors_q = tg[0, -1], er[0, -1], q_out[0, -1].copy()
+        return q_out[0], nsolve[0]
 
     def retarget(self, human_data, offset_to_ground=False):
         """One frame (reference :139-185): warm-started from the previous call, returns qpos f64[nq]."""
-        self.update_targets(human_data, offset_to_ground)
-        q_out, nsolve, status = self.hip_solver.retarget_streams(
-            self.configuration.data.qpos[None], self._raw_frame[None, None],
-            flags=_lib.FLAG_OFFSET_TO_GROUND if offset_to_ground else 0)
-        if status[0] != 0:
-            raise RuntimeError(f"IK failed (status {int(status[0])}): QP not solvable / non-finite input")
-        self.last_num_solves = nsolve[0, 0].copy()
-        self.configuration.data.qpos = q_out[0, 0].copy()
-        return self.configuration.data.qpos.copy()
+        human_data = self.to_numpy(human_data)
+        frame = self.pack_frame(human_data)
+        q, ns = self._run(frame[None], offset_to_ground, list(human_data.keys()))
+        self.last_num_solves = ns[0].copy()
+        return q[0].copy()
 
     def retarget_packed(self, frame: np.ndarray, offset_to_ground=False) -> np.ndarray:
         """:meth:`retarget` for a frame that is already packed (``f64[nhuman, 7]``, rows in
@@ -221,32 +243,25 @@ class GeneralMotionRetargeting:
         frame = np.ascontiguousarray(frame, dtype=np.float64)
         if frame.shape != (len(self._human_names), 7):
             raise ValueError(f"packed frame must be [{len(self._human_names)}, 7], got {frame.shape}")
-        self._raw_frame = frame
-        self._scaled_src, self._scaled_cache = None, None
-        q_out, nsolve, status = self.hip_solver.retarget_streams(
-            self.configuration.data.qpos[None], frame[None, None],
-            flags=_lib.FLAG_OFFSET_TO_GROUND if offset_to_ground else 0)
-        if status[0] != 0:
-            raise RuntimeError(f"IK failed (status {int(status[0])}): QP not solvable / non-finite input")
-        self.last_num_solves = nsolve[0, 0].copy()
-        self.configuration.data.qpos = q_out[0, 0].copy()
-        return self.configuration.data.qpos.copy()
+        q, ns = self._run(frame[None], offset_to_ground)
+        self.last_num_solves = ns[0].copy()
+        return q[0].copy()
 
     def retarget_clip(self, frames, offset_to_ground=False) -> np.ndarray:
         """All frames of one clip in ONE launch (time loop on device); continues from the current
         configuration exactly like calling :meth:`retarget` per frame.  ``frames`` is a sequence of
         ``human_data`` dicts or an array ``[T, nhuman, 7]``.  Returns ``qpos f64[T, nq]``."""
-        human = frames if isinstance(frames, np.ndarray) else self.pack_frames(frames)
+        key_order = None
+        if isinstance(frames, np.ndarray):
+            human = np.ascontiguousarray(frames, dtype=np.float64)
+        else:
+            human = self.pack_frames(frames)
+            key_order = list(frames[-1].keys()) if len(frames) else None
         if human.shape[0] == 0:
             return np.zeros((0, self.model.nq))
-        q_out, nsolve, status = self.hip_solver.retarget_streams(
-            self.configuration.data.qpos[None], human[None],
-            flags=_lib.FLAG_OFFSET_TO_GROUND if offset_to_ground else 0)
-        if status[0] != 0:
-            raise RuntimeError(f"IK failed (status {int(status[0])})")
-        self.last_num_solves = nsolve[0].copy()
-        self.configuration.data.qpos = q_out[0, -1].copy()
-        return q_out[0]
+        q, ns = self._run(human, offset_to_ground, key_order)
+        self.last_num_solves = ns.copy()
+        return q
 
     def retarget_streams(self, human: np.ndarray, q0: Optional[np.ndarray] = None, lens=None,
                          offset_to_ground=False):
@@ -256,21 +271,17 @@ class GeneralMotionRetargeting:
         S = human.shape[0]
         if q0 is None:
             q0 = np.broadcast_to(self.model.qpos0, (S, self.model.nq)).copy()
-        return self.hip_solver.retarget_streams(
-            q0, human, lens=lens, flags=_lib.FLAG_OFFSET_TO_GROUND if offset_to_ground else 0)
+        return self.hip_solver.retarget_streams(q0, human, lens=lens, flags=self._flags(offset_to_ground))
 
-    # ---- errors (reference :188-200), NumPy ------------------------------------------------
+    # ---- errors (reference :188-200): evaluated by the kernel ------------------------------
     def _error(self, stage: int) -> float:
-        if self.scaled_human_data is None:
+        if getattr(self, "_raw_frame", None) is None:
             raise TargetNotSet("retarget()/update_targets() has not been called")
-        st = self._tables.stages[stage]
-        xpos, xquat = fk_numpy(self.model, self.configuration.data.qpos)
-        es = []
-        for fr, hb in zip(st.frame_names, st.human_names):
-            b = self.model.body_id(fr)
-            pos, quat = self.scaled_human_data[hb]
-            es.append(_se3_log_rel(xpos[b], xquat[b], np.asarray(pos), np.asarray(quat)))
-        return float(np.linalg.norm(np.concatenate(es)))
+        if not self._tables.use_stage[stage]:
+            raise ValueError("need at least one array to concatenate")    # the reference's empty task list (:190,:197)
+        if self._errors is None or not np.array_equal(self._errors_q, self.configuration.data.qpos):
+            self._evaluate()
+        return float(self._errors[stage])
 
     def error1(self):
         return self._error(0)
@@ -278,7 +289,10 @@ class GeneralMotionRetargeting:
     def error2(self):
         return self._error(1)
 
-    # ---- preprocessing helpers (reference :203-270), NumPy ---------------------------------
+    # ---- preprocessing helpers (reference :203-270) ----------------------------------------------
+    # Public-by-convention NumPy methods of the reference class, kept for callers that use them directly.  The
+    # retargeting path does not: the kernel preprocesses the raw packed frame (and scaled_human_data above is
+    # its output).
     def to_numpy(self, human_data):
         for body_name in human_data.keys():
             human_data[body_name] = [np.asarray(human_data[body_name][0]), np.asarray(human_data[body_name][1])]
@@ -303,9 +317,9 @@ class GeneralMotionRetargeting:
             q = np.asarray(quat, dtype=np.float64)
             q = q / np.linalg.norm(q)
             qo = np.asarray(rot_offsets[name], dtype=np.float64)
-            uq = quat_mul(q, qo / np.linalg.norm(qo))
+            uq = _quat_mul(q, qo / np.linalg.norm(qo))
             uq = uq / np.linalg.norm(uq)
-            out[name] = [pos + quat_rotate(uq, np.asarray(pos_offsets[name], dtype=np.float64)), uq]
+            out[name] = [pos + _quat_rotate(uq, np.asarray(pos_offsets[name], dtype=np.float64)), uq]
         return out
 
     def offset_human_data_to_ground(self, human_data):

@@ -33,6 +33,8 @@ extern "C" {
 
 /* retarget flags */
 #define GMR_FLAG_OFFSET_TO_GROUND 1 /* retarget(human_data, offset_to_ground=True), motion_retarget.py:139 */
+#define GMR_FLAG_EVAL_ONLY 2        /* update_targets() without solve: preprocess + residual norms only, q_out = q in
+                                       (motion_retarget.py:117-136 followed by error1()/error2(), :188-200)          */
 
 /* per-stream status written by the IK kernel */
 #define GMR_STATUS_OK 0
@@ -92,12 +94,18 @@ int gmr_solver_set_waves(gmr_solver_t* solver, int waves_per_stream);
  *   q_out   f64 [S][T][nq]         qpos after each frame (what retarget() returns, :185)
  *   nsolve  i32 [S][T][2]          solve_ik calls per stage (1 + loop iterations, :147-161)
  *   status  i32 [S]                GMR_STATUS_*
+ *   tgt_out f64 [S][T][nhuman][7]  or NULL: the preprocessed targets of every frame, i.e. `scaled_human_data`
+ *                                  = the poses handed to task.set_target (:117-136, :203-270), as the kernel
+ *                                  computed them (absent bodies stay NaN rows)
+ *   err_out f64 [S][T][2]          or NULL: error1() / error2() (:188-200) at the configuration each frame
+ *                                  ends with (0 for a stage the config does not use)
  */
 int gmr_retarget_streams_dev(gmr_solver_t* solver, int S, int T, const double* d_q0, const double* d_human,
                              const int32_t* d_len, int flags, double* d_q_out, int32_t* d_nsolve,
-                             int32_t* d_status, void* stream);
+                             int32_t* d_status, double* d_tgt_out, double* d_err_out, void* stream);
 int gmr_retarget_streams(gmr_solver_t* solver, int S, int T, const double* q0, const double* human,
-                         const int32_t* len, int flags, double* q_out, int32_t* nsolve, int32_t* status);
+                         const int32_t* len, int flags, double* q_out, int32_t* nsolve, int32_t* status,
+                         double* tgt_out, double* err_out);
 /* LDS bytes per stream of the IK kernel for this solver (occupancy reporting). */
 int gmr_retarget_lds_bytes(const gmr_solver_t* solver);
 

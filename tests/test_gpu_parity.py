@@ -192,6 +192,102 @@ def test_shim_per_frame_equals_clip_equals_oracle(hip, oracle, g1):
         GeneralMotionRetargeting("smplx", "unitree_g1").retarget(bad)
 
 
+def test_hip_preprocess_matches_reference_golden(hip):
+    """H2/H3 on the HIP path, pinned DIRECTLY: the kernel's own preprocessed targets (tgt_out = what it hands to
+    the residuals, i.e. task.set_target's poses / scaled_human_data, reference motion_retarget.py:117-136,203-270)
+    against the fixtures generated by running the reference's Python -- all 14 configs x 2 heights x 2 ground flags.
+    Tolerance 2e-15 absolute on metres / unit quaternions (the fixture values are < 2 in magnitude: <= 9 ulp;
+    the device contracts multiply-adds, NumPy does not)."""
+    from conftest import ALL_CONFIGS, GOLDEN, get_setup
+    import os
+    G = np.load(os.path.join(GOLDEN, "g_pre.npz"))
+    worst = 0.0
+    for src, robot in ALL_CONFIGS:
+        for hname, height in (("none", None), ("h162", 1.62)):
+            su = get_setup(src, robot, height)
+            sol = hip.Solver(su.mb, su.ts)
+            q0 = su.model.qpos0[None].copy()
+            for ground in (0, 1):
+                tag = f"{src}__{robot}__{hname}__g{ground}"
+                raw = G[tag + "__raw"]
+                exp = G[tag + "__scaled"]
+                flags = (hip.FLAG_OFFSET_TO_GROUND if ground else 0)
+                # once without a solve (update_targets() alone) and once as part of a real retarget() launch
+                for fl in (flags | hip.FLAG_EVAL_ONLY, flags):
+                    q, ns, st, tg, er = sol.retarget_streams(q0, raw[None, None], flags=fl, want_targets=True,
+                                                             want_errors=True)
+                    got = tg[0, 0]
+                    # (fbx has no body named *foot*: with offset_to_ground the reference's `lowest` stays +inf and
+                    # every target z becomes -inf (:252-270); the fixture holds that, the kernel reproduces it and
+                    # then reports the stream as failed instead of solving on non-finite targets)
+                    both_inf = np.isinf(got) & np.isinf(exp) & (np.sign(got) == np.sign(exp))
+                    assert np.array_equal(np.isfinite(got) | both_inf, np.ones_like(got, dtype=bool)), tag
+                    assert np.array_equal(np.isinf(got), np.isinf(exp)), tag
+                    with np.errstate(invalid="ignore"):
+                        d = np.where(both_inf, 0.0, np.abs(got - exp))
+                    worst = max(worst, float(d.max()))
+                    assert d.max() <= 2e-15, (tag, float(d.max()))
+                    assert st[0] == (0 if np.isfinite(exp).all() or (fl & hip.FLAG_EVAL_ONLY) else hip.STATUS_QP_FAILED), tag
+                    if fl & hip.FLAG_EVAL_ONLY:
+                        assert (ns == 0).all() and np.abs(q[0, 0] - q0[0]).max() <= 1e-15
+            sol.close()
+    print("max |tgt_out - reference scaled_human_data| =", worst)
+
+
+def test_shim_scaled_human_data_and_errors_come_from_the_kernel(hip, oracle, g1):
+    """scaled_human_data / error1() / error2() (reference :118-124, :188-200) follow the LAST retargeted frame for
+    every entry point, and after update_targets() alone they come from a solve-free launch."""
+    import os
+    from conftest import GOLDEN
+    from general_motion_retargeting_amd import GeneralMotionRetargeting, synth
+    from general_motion_retargeting_amd.motion_retarget import TargetNotSet
+    G = np.load(os.path.join(GOLDEN, "g_pre.npz"))
+    g = GeneralMotionRetargeting("smplx", "unitree_g1", actual_human_height=1.62)
+    tag = "smplx__unitree_g1__h162__g1"
+    names = [str(x) for x in G[tag + "__names"]]
+    raw = G[tag + "__raw"]
+    hd = {n: (raw[i, :3].copy(), raw[i, 3:].copy()) for i, n in enumerate(names)}
+    hd["not_in_scale_table"] = (np.zeros(3), np.array([1.0, 0, 0, 0]))
+    g.update_targets(hd, offset_to_ground=True)
+    shd = g.scaled_human_data
+    assert "not_in_scale_table" not in shd and list(shd)[0] == g.human_root_name
+    got = np.array([np.concatenate(shd[n]) for n in names])
+    assert np.abs(got - G[tag + "__scaled"]).max() <= 2e-15
+    # errors at an arbitrary configuration, no solve: the oracle's stage error on the oracle's targets
+    human, q0, truth = synth.make_streams(g1.model, g1.tt, 1, 5, seed=9, return_truth=True)
+    g = GeneralMotionRetargeting("smplx", "unitree_g1")
+    with pytest.raises(TargetNotSet):
+        g.error1()
+    frames = synth.streams_to_dicts(g1.tt, human[0])
+    g.update_targets(frames[1])
+    g.configuration.update(truth[0, 0])
+    tgt = oracle.preprocess(g1.ts, human[0, 1])
+    for stage, fn in ((0, g.error1), (1, g.error2)):
+        _, E = oracle.stage_error(g1.mb, g1.ts, stage, truth[0, 0], tgt)
+        assert abs(fn() - E) < 1e-12
+    assert np.array_equal(g.configuration.q, truth[0, 0])            # evaluation does not move the configuration
+    # after retarget(): the errors of the configuration the frame ended with
+    g = GeneralMotionRetargeting("smplx", "unitree_g1")
+    q = None
+    for t in range(3):
+        q = g.retarget(frames[t])
+    tgt = oracle.preprocess(g1.ts, human[0, 2])
+    for stage, fn in ((0, g.error1), (1, g.error2)):
+        _, E = oracle.stage_error(g1.mb, g1.ts, stage, q, tgt)
+        assert abs(fn() - E) < 1e-10
+    assert np.abs(np.concatenate(g.scaled_human_data["pelvis"]) - tgt[g1.tt.human_names.index("pelvis")]).max() < 1e-14
+    # after retarget_clip / retarget_packed: still the last frame's (ADVICE: stale targets)
+    qc = g.retarget_clip(frames[3:5])
+    tgt = oracle.preprocess(g1.ts, human[0, 4])
+    _, E = oracle.stage_error(g1.mb, g1.ts, 1, qc[-1], tgt)
+    assert abs(g.error2() - E) < 1e-10
+    assert np.abs(g.scaled_human_data["pelvis"][0] - tgt[g1.tt.human_names.index("pelvis"), :3]).max() < 1e-14
+    qp = g.retarget_packed(human[0, 0])
+    tgt = oracle.preprocess(g1.ts, human[0, 0])
+    _, E = oracle.stage_error(g1.mb, g1.ts, 0, qp, tgt)
+    assert abs(g.error1() - E) < 1e-10 and set(g.scaled_human_data) == set(g1.tt.human_names)
+
+
 def test_shim_offset_to_ground(hip, oracle, g1):
     from general_motion_retargeting_amd import GeneralMotionRetargeting, synth
     human, q0 = synth.make_streams(g1.model, g1.tt, 1, 4, seed=2)

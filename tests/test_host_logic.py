@@ -45,17 +45,58 @@ def test_constructor_attributes_match_reference_surface():
     assert g._taskset_blob["damping"][0] == 0.25
 
 
-def test_error_functions_follow_reference_definition(oracle, g1):
+def test_error_functions_need_targets():
     g = GeneralMotionRetargeting("smplx", "unitree_g1")
-    human, q0, truth = synth.make_streams(g1.model, g1.tt, 1, 3, seed=9, return_truth=True)
     with pytest.raises(TargetNotSet):
         g.error1()
-    g.update_targets(synth.streams_to_dicts(g1.tt, human[0])[1])
-    g.configuration.update(truth[0, 0])
-    tgt = oracle.preprocess(g1.ts, human[0, 1])
-    for stage, fn in ((0, g.error1), (1, g.error2)):
-        _, E = oracle.stage_error(g1.mb, g1.ts, stage, truth[0, 0], tgt)
-        assert abs(fn() - E) < 1e-12
+    assert g.scaled_human_data is None
+    k = GeneralMotionRetargeting("smplx", "kuavo_s45")      # use_ik_match_table2 = false: an empty task list
+    k._raw_frame = np.zeros((len(k.human_body_names), 7))
+    with pytest.raises(ValueError):
+        k.error2()
+
+
+def test_binding_accepts_stream_objects(monkeypatch):
+    """Every *_dev wrapper and Event.record take a _lib.Stream, a raw pointer or None (one helper)."""
+    from general_motion_retargeting_amd import _lib
+    import ctypes as C
+
+    class S(_lib.Stream):
+        def __init__(self):             # no device here: a Stream object around a fake handle
+            self.ptr = C.c_void_p(0x1234)
+
+        def __del__(self):
+            pass
+    s = S()
+    assert _lib._s(s).value == 0x1234 and _lib._s(None) is None and _lib._s(s.ptr) is s.ptr
+    seen = {}
+
+    class FakeLib:
+        def __getattr__(self, name):
+            def f(*a):
+                seen[name] = a
+                return 0
+            return f
+    monkeypatch.setattr(_lib, "lib", lambda: FakeLib())
+    ev = _lib.Event.__new__(_lib.Event)
+    ev.ptr = C.c_void_p(1)
+    ev.record(s)
+    assert seen["gmr_event_record"][1].value == 0x1234
+    fk = _lib.FkHandle.__new__(_lib.FkHandle)
+    fk.handle = C.c_void_p(2)
+    fk.fk_dev(4, None, None, None, None, stream=s)
+    assert seen["gmr_fk_batch_dev"][-1].value == 0x1234
+    sx = _lib.SmplxHandle.__new__(_lib.SmplxHandle)
+    sx.handle = C.c_void_p(3)
+    sx.align_dev(1, 55, None, None, 1, None, None, stream=s)
+    sx.joints_dev(1, None, None, None, None, stream=s)
+    assert seen["gmr_smplx_align_dev"][-1].value == 0x1234 and seen["gmr_smplx_joints_dev"][-1].value == 0x1234
+    so = _lib.Solver.__new__(_lib.Solver)
+    so.handle = C.c_void_p(4)
+    so.retarget_streams_dev(1, 1, None, None, None, 0, None, None, None, s)
+    assert seen["gmr_retarget_streams_dev"][-1].value == 0x1234
+    for o in (ev, fk, sx, so):          # fake handles: nothing to release
+        o.ptr = o.handle = None
 
 
 def test_lpt_partition_properties():
