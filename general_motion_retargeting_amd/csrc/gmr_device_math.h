@@ -182,6 +182,127 @@ __device__ __forceinline__ void se3_jlinv_aux(const double e[6], const double au
   for (int i = 0; i < 9; i++) { A.a[i] = Am.a[i]; B.a[i] = -AQA.a[i]; }
 }
 
+// ---- lean variants for the hot loop -----------------------------------------------------------------------------
+// The residual of one task needs log(q) of a UNIT quaternion q = (w, v): with n = |v| the half angle is
+// h = atan2(n, |w|), so sin h = n and cos h = |w| are already there -- the closed forms of V^-1 and Jl^-1 need no
+// further sin / cos / sqrt, and one reciprocal (1 / t) serves all divisions.  Same functions and the same series
+// switches as se3_log_rel / se3_jlinv_aux above (mink's formulas, App. A.5); values agree to a few ulp.
+
+// 1 / x for a normal-range x: v_rcp_f64 seed + two Newton steps (~1 ulp)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = fma(fma(-x, y, 1.0), y, y);
+  y = fma(fma(-x, y, 1.0), y, y);
+  return y;
+}
+
+// sin and cos for |x| up to a few hundred (joint angles, half angles): Cody-Waite reduction by pi/2 in two pieces,
+// fdlibm's kernel polynomials on [-pi/4, pi/4] (< 1 ulp there); no large-argument path, no tables
+__device__ __forceinline__ void sincos_small(double x, double* sn, double* cs) {
+  const double k = rint(x * 6.36619772367581382433e-01);              // 2 / pi
+  double r = fma(-k, 1.57079632673412561417e+00, x);                  // first 33 bits of pi / 2: exact product
+  r = fma(-k, 6.07710050650619224932e-11, r);
+  const double z = r * r;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                                 2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                               8.33333333332248946124e-03), -1.66666666666666324348e-01);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                                 -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                               -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double s = fma(r * z, ps, r);
+  const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int q = (int)k;
+  const double ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+  *sn = (q & 2) ? -ss : ss;
+  *cs = ((q + 1) & 2) ? -cc : cc;
+}
+
+// e = log(T_wb^-1 T_wt) = [V^-1(w) p_bt ; w]; aux = {a, sin t, cos t, t, 1/t} (t = |w|) for se3_jlinv_aux5
+__device__ __forceinline__ void se3_log_rel5(d3 pb, d4 qb, d3 pt, d4 qt, double e[6], double aux[5]) {
+  const d4 q = qmul(qconj(qb), qt);
+  const d3 pbt = qrot_inv(qb, pt - pb);
+  // SO3 log, mink / jaxlie branch structure (App. A.5)
+  const double n2 = q.x * q.x + q.y * q.y + q.z * q.z;
+  const double cw = fabs(q.w);
+  double f, sh = 0.0, ch = 1.0, inv_sh = 0.0, half = 0.0;   // half angle h, sin h, cos h, 1 / sin h
+  if (n2 < 1e-10) {
+    f = 2.0 / q.w - 2.0 / 3.0 * n2 / (q.w * q.w * q.w);
+  } else {
+    const double inv_n = fast_rsqrt(n2);
+    sh = n2 * inv_n; ch = cw; inv_sh = inv_n;
+    half = atan2(sh, ch);
+    bool neg = q.w < 0.0;
+    if (cw < 1e-10) {           // mink sets the angle to pi exactly here: sin(pi/2), cos(pi/2) as libm returns them
+      half = 1.57079632679489661923; sh = 1.0; ch = 6.123233995736766e-17; inv_sh = 1.0;
+      neg = !(q.w > 0.0);
+    }
+    f = 2.0 * half * inv_n;
+    if (neg) f = -f;
+  }
+  const d3 w = {f * q.x, f * q.y, f * q.z};
+  const double t2 = dot(w, w);
+  double a;
+  if (t2 < 1e-2) {
+    aux[1] = 0.0; aux[2] = 1.0; aux[3] = 0.0; aux[4] = 0.0;
+    a = 1.0 / 12.0 + t2 * (1.0 / 720.0 + t2 * (1.0 / 30240.0 + t2 * (1.0 / 1209600.0 + t2 / 47900160.0)));
+  } else {                      // t >= 0.1: the main branch above was taken
+    const double t = 2.0 * half, inv_t = fast_rcp(t);
+    aux[1] = 2.0 * sh * ch;
+    aux[2] = 1.0 - 2.0 * sh * sh;
+    aux[3] = t; aux[4] = inv_t;
+    a = (sh - half * ch) * inv_sh * (inv_t * inv_t);      // (1 - (t/2) cot(t/2)) / t^2
+  }
+  aux[0] = a;
+  // V^-1 p = p - 0.5 w x p + a w x (w x p)
+  const d3 wp = cross(w, pbt);
+  const d3 wwp = cross(w, wp);
+  const d3 v = pbt - 0.5 * wp + a * wwp;
+  e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = w.x; e[4] = w.y; e[5] = w.z;
+}
+
+// Jl^-1(e) = [[A, B], [0, A]] as se3_jlinv_aux, with t and 1/t handed over by se3_log_rel5 (no sqrt, no division)
+__device__ __forceinline__ void se3_jlinv_aux5(const double e[6], const double aux[5], m3& A, m3& B) {
+  d3 rho = {e[0], e[1], e[2]}, w = {e[3], e[4], e[5]};
+  double t2 = dot(w, w);
+#pragma unroll
+  for (int i = 0; i < 9; i++) { A.a[i] = 0.0; B.a[i] = 0.0; }
+  A.a[0] = A.a[4] = A.a[8] = 1.0;
+  if (t2 < 1e-10) return;
+  const double a = aux[0];
+  double c1, c2, c3;
+  if (t2 < 1e-2) {
+    c1 = 1.0 / 6.0 - t2 / 120.0 + t2 * t2 / 5040.0 - t2 * t2 * t2 / 362880.0;
+    c2 = -1.0 / 24.0 + t2 / 720.0 - t2 * t2 / 40320.0 + t2 * t2 * t2 / 3628800.0;
+    c3 = -1.0 / 120.0 + t2 / 5040.0 - t2 * t2 / 362880.0 + t2 * t2 * t2 / 39916800.0;
+  } else {
+    const double t = aux[3], it = aux[4], sn = aux[1], cs = aux[2];
+    const double it2 = it * it;
+    c1 = (t - sn) * it2 * it;
+    c2 = (1.0 - 0.5 * t2 - cs) * it2 * it2;
+    c3 = (t - sn - t2 * t / 6.0) * it2 * it2 * it;
+  }
+  const double c4 = -0.5 * (c2 - 3.0 * c3);
+  const double s = dot(w, rho);
+  d3 n = cross(w, rho), m = cross(w, n);
+  const double wv[3] = {w.x, w.y, w.z}, rv[3] = {rho.x, rho.y, rho.z};
+  const double k1 = (c1 + c2) * s;
+  d3 sq = {0.5 * rho.x - k1 * w.x - c2 * m.x, 0.5 * rho.y - k1 * w.y - c2 * m.y, 0.5 * rho.z - k1 * w.z - c2 * m.z};
+  m3 Q = skew(sq);
+  const double dq = -2.0 * c1 * s + 2.0 * c4 * s * t2, kw = -2.0 * c4 * s;
+  m3 Am = skew(d3{-0.5 * w.x, -0.5 * w.y, -0.5 * w.z});
+  const double da = 1.0 - a * t2;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      Q.a[3 * i + j] += c1 * (rv[i] * wv[j] + wv[i] * rv[j]) + kw * wv[i] * wv[j] + (i == j ? dq : 0.0);
+      Am.a[3 * i + j] += a * wv[i] * wv[j] + (i == j ? da : 0.0);
+    }
+  m3 AQA = mmul(mmul(Am, Q), Am);
+#pragma unroll
+  for (int i = 0; i < 9; i++) { A.a[i] = Am.a[i]; B.a[i] = -AQA.a[i]; }
+}
+
 // wave64 butterfly reductions (deterministic, every lane gets the result)
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -82,6 +82,7 @@ constexpr WideLds wide_lds() {
 constexpr int WD_LDS_BYTES = wide_lds().n_double * 8;
 static_assert(7 * 18 <= 6 * WD_P && 7 * WD_NB + 1 <= 6 * WD_P, "aliases must fit");
 static_assert(7 * WD_NHUM + 1 <= 18 * WD_K, "raw frame must fit the M region");
+static_assert(5 * WD_K <= WD_P, "eaux must fit the cpart region");
 
 // ---- global image (offsets in bytes; every section 16-byte aligned) ----------------------------------------------
 // per-lane sections are indexed by the lane that consumes them, so that a phase starts with a few coalesced loads

@@ -6,7 +6,6 @@ Not part of the product or of the bench; read SHARES, not absolute time (stamps 
 """
 import ctypes as C
 import os
-import subprocess
 import sys
 
 import numpy as np
@@ -27,9 +26,8 @@ def main():
     pkg = os.path.join(ROOT, "general_motion_retargeting_amd")
     so = os.path.join(pkg, "libgmrhip_prof.so")
     if not os.path.exists(so) or os.environ.get("REBUILD"):
-        srcs = [os.path.join(pkg, "csrc", f) for f in ("gmr_ik.hip", "gmr_fk.hip", "gmr_smplx.hip", "gmr_abi.hip")]
-        subprocess.check_call(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-                               "-DGMR_IK_PROFILE", "-o", so] + srcs)
+        from general_motion_retargeting_amd import build
+        build.build_variant("prof", ["-DGMR_IK_PROFILE"])
     _lib.LIB_PATH = so
     L = _lib.lib()
     model = load_robot(params.ROBOT_XML_DICT["unitree_g1"])
