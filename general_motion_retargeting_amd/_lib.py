@@ -68,6 +68,17 @@ _SIGS = {
                                       C.c_void_p, C.c_void_p]),
     "gmr_smplx_align": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_void_p]),
+    "gmr_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "gmr_comm_destroy": (C.c_int, [C.c_void_p]),
+    "gmr_comm_rank": (C.c_int, [C.c_void_p]),
+    "gmr_comm_world": (C.c_int, [C.c_void_p]),
+    "gmr_comm_broadcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "gmr_comm_broadcast_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "gmr_comm_barrier": (C.c_int, [C.c_void_p]),
+    "gmr_comm_allreduce_max": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "gmr_comm_allreduce_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "gmr_comm_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "gmr_bootstrap_exchange": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_size_t, C.c_double]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgmrhip.so")
 OBJ = os.path.join(os.path.dirname(HERE), "build", "obj")
-SOURCES = ["gmr_ik.hip", "gmr_ik_wide.hip", "gmr_fk.hip", "gmr_smplx.hip", "gmr_abi.hip"]
+SOURCES = ["gmr_ik.hip", "gmr_ik_wide.hip", "gmr_fk.hip", "gmr_smplx.hip", "gmr_comm.hip", "gmr_abi.hip"]
 HEADERS = ["gmr_device_math.h", "gmr_ik_layout.h", "gmr_ik_wide_layout.h", "gmr_ik_prof.h", "gmr_ik_tree.h",
            "gmr_fk_tree.h", "gmr_internal.h", "../../include/gmr_hip.h", "../../include/gmr_types.h"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
@@ -57,7 +57,7 @@ def _object(src: str, defines, force: bool, verbose: bool) -> str:
 
 
 def _link(objs, out: str) -> str:
-    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out + ".tmp"] + objs)
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out + ".tmp"] + objs + ["-ldl"])
     os.replace(out + ".tmp", out)
     return out
 

@@ -158,14 +158,15 @@ __device__ __forceinline__ double errors_wave(const LT& L, double* sm, const sho
     int b = task_body[lane], h = task_human[lane];
     const double* x = sm + L.o.xa + 7 * b;
     const double* tg = sm + L.o.tgt + 7 * h;
-    double e[6], aux[3];
-    se3_log_rel(d3{x[0], x[1], x[2]}, d4{x[3], x[4], x[5], x[6]}, d3{tg[0], tg[1], tg[2]},
-                d4{tg[3], tg[4], tg[5], tg[6]}, e, aux);
+    double e[6], aux[5];
+    se3_log_rel5(d3{x[0], x[1], x[2]}, d4{x[3], x[4], x[5], x[6]}, d3{tg[0], tg[1], tg[2]},
+                 d4{tg[3], tg[4], tg[5], tg[6]}, e, aux);
     double* eo = sm + L.o.e + 6 * lane;
 #pragma unroll
     for (int r = 0; r < 6; r++) { eo[r] = e[r]; ss += e[r] * e[r]; }
-    double* ao = sm + L.o.eaux + 3 * lane;     // a, sin|w|, cos|w|: reused by the Jl^-1 phase
-    ao[0] = aux[0]; ao[1] = aux[1]; ao[2] = aux[2];
+    double* ao = sm + L.o.eaux + 5 * lane;     // a, sin|w|, cos|w|, |w|, 1/|w|: reused by the Jl^-1 phase
+#pragma unroll
+    for (int r = 0; r < 5; r++) ao[r] = aux[r];
   }
   ss = row0_sum(ss);                 // tasks live in lanes 0..K-1, K <= 16
   WSYNC();
@@ -196,10 +197,10 @@ __device__ __forceinline__ double jlog_phase(const LT& L, double* sm, int stage,
     double ee[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ee[r] = e[r];
-    const double* ax = sm + L.o.eaux + 3 * lane;
-    const double aux[3] = {ax[0], ax[1], ax[2]};
+    const double* ax = sm + L.o.eaux + 5 * lane;
+    const double aux[5] = {ax[0], ax[1], ax[2], ax[3], ax[4]};
     m3 A, B;
-    se3_jlinv_aux(ee, aux, A, B);
+    se3_jlinv_aux5(ee, aux, A, B);
     double* M = sm + L.o.M + 18 * lane;
 #pragma unroll
     for (int i = 0; i < 9; i++) { M[i] = -A.a[i]; M[9 + i] = -B.a[i]; }
@@ -699,7 +700,7 @@ template <class LT>
 __device__ __forceinline__ void hinge_sincos(const LT& L, double* sm, int lane) {
   if (lane >= 6 && lane < L.nv) {
     double s, c;
-    sincos(0.5 * (sm + L.o.q)[7 + lane - 6], &s, &c);
+    sincos_small(0.5 * (sm + L.o.q)[7 + lane - 6], &s, &c);
     double* sc = sm + L.o.hsc + 2 * (lane - 6);
     sc[0] = s; sc[1] = c;
   }
@@ -722,14 +723,14 @@ __device__ __forceinline__ void integrate_wave(const LT& L, double* sm, double d
     q[0] += dq[0]; q[1] += dq[1]; q[2] += dq[2];
     const double n2 = dq[3] * dq[3] + dq[4] * dq[4] + dq[5] * dq[5];
     rotate = n2 >= 1e-30 * dt * dt;
-    if (rotate) { inv = rsqrt(n2); half = 0.5 * (n2 * inv); }
+    if (rotate) { inv = fast_rsqrt(n2); half = 0.5 * (n2 * inv); }
   } else if (hinge) {
     const double th = q[7 + lane - 6] + dq[lane];
     q[7 + lane - 6] = th;
     half = 0.5 * th;
   }
   double s, c;
-  sincos(half, &s, &c);
+  sincos_small(half, &s, &c);
   if (base) {
     d4 quat = qnormalize(d4{q[3], q[4], q[5], q[6]});
     if (rotate) quat = qmul(quat, d4{c, dq[3] * inv * s, dq[4] * inv * s, dq[5] * inv * s});

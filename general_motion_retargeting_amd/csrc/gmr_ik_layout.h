@@ -65,7 +65,7 @@ constexpr IkOffsets ik_offsets(int nvp, int nw) {
   L.xa = o; o += 7 * cp.nb + 1;                    // FK result; the second buffer of the FK rounds aliases Jw
   L.xaxis = o; o += 3 * cp.nb;
   L.tgt = o; o += 7 * cp.nhum + 1;
-  L.e = o; o += 6 * cp.k; L.eaux = o; o += 3 * cp.k; L.we = o; o += 6 * cp.k;
+  L.e = o; o += 6 * cp.k; L.eaux = o; o += 5 * cp.k; L.we = o; o += 6 * cp.k;
   L.M = o; o += ik_max(18 * cp.k, 7 * cp.nhum + 1);
   L.raw = L.M;                                     // the raw frame is consumed by the preprocess step, before any solve
   if (o & 1) o++;                                  // Jw rows (48 B) are read as three 16-B pieces

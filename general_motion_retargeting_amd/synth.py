@@ -97,9 +97,21 @@ def make_trajectory(model: RobotModel, rng: np.random.Generator, T: int, fps: fl
     return q
 
 
-def make_streams(model: RobotModel, tt: TaskTables, S: int, T: int, seed: int = 0,
-                 pos_noise: float = 0.01, rot_noise_deg: float = 2.0, return_truth: bool = False):
-    """Synthetic batch: human f64[S,T,nhuman,7], q0 f64[S,nq] (stream s uses seed ``seed + s``)."""
+def _draw_stream(model: RobotModel, rng: np.random.Generator, T: int, nhum: int, pos_noise: float, rot_noise: float):
+    """The random draws of ONE stream, in the generator's fixed order: (q*[T, nq], position noise [nhum, T, 3],
+    rotation-vector noise [nhum, T, 3])."""
+    q = make_trajectory(model, rng, T)
+    pn = np.empty((nhum, T, 3))
+    rn = np.empty((nhum, T, 3))
+    for i in range(nhum):
+        pn[i] = rng.normal(0.0, pos_noise, size=(T, 3))
+        rn[i] = rng.normal(0.0, rot_noise, size=(T, 3))
+    return q, pn, rn
+
+
+def _make_chunk(args):
+    """Streams with the given seeds (one per stream) -> (human[n, T, nhum, 7], truth[n, T, nq])."""
+    model, tt, seeds, T, pos_noise, rot_noise = args
     names = tt.human_names
     nhum = len(names)
     # robot frame whose pose defines each human body (table 1 first, then table 2, else the root)
@@ -108,39 +120,60 @@ def make_streams(model: RobotModel, tt: TaskTables, S: int, T: int, seed: int = 
         for fr, hb in zip(st.frame_names, st.human_names):
             frame_of[hb] = model.body_id(fr)
     root_i = names.index(tt.human_root_name)
-    human = np.zeros((S, T, nhum, 7))
-    truth = np.zeros((S, T, model.nq))
     scale = np.array([tt.scale_table[n] for n in names])
-    for s in range(S):
-        rng = np.random.default_rng(seed + s)
-        q = make_trajectory(model, rng, T)
-        truth[s] = q
-        xpos, xquat = fk_numpy(model, q)
-        tp = np.zeros((T, nhum, 3))
-        tq = np.zeros((T, nhum, 4))
-        for i, n in enumerate(names):
-            b = frame_of.get(n, 0)
-            tp[:, i] = xpos[:, b] + rng.normal(0.0, pos_noise, size=(T, 3))
-            nq_ = rotvec_quat(rng.normal(0.0, np.deg2rad(rot_noise_deg), size=(T, 3)))
-            tq[:, i] = quat_mul(xquat[:, b], nq_)
-        # invert offset_human_data: q_h = q_t * conj(q_off); p_scaled = p_t - R(q_t) off
-        ps = np.zeros_like(tp)
-        for i, n in enumerate(names):
-            off = tt.pos_offsets1.get(n, np.zeros(3))
-            qo = tt.rot_offsets1.get(n, np.array([1.0, 0, 0, 0]))
-            human[s, :, i, 3:] = quat_mul(tq[:, i], np.broadcast_to(quat_conj(qo), (T, 4)))
-            ps[:, i] = tp[:, i] - quat_rotate(tq[:, i], np.broadcast_to(off, (T, 3)))
-        # invert scale_human_data
-        raw_root = ps[:, root_i] / scale[root_i]
-        for i in range(nhum):
-            if i == root_i:
-                human[s, :, i, :3] = raw_root
-            else:
-                human[s, :, i, :3] = (ps[:, i] - ps[:, root_i]) / scale[i] + raw_root
+    body = np.array([frame_of.get(n, 0) for n in names])
+    off = np.array([tt.pos_offsets1.get(n, np.zeros(3)) for n in names])
+    qoc = np.array([quat_conj(tt.rot_offsets1.get(n, np.array([1.0, 0, 0, 0]))) for n in names])
+    n = len(seeds)
+    human = np.zeros((n, T, nhum, 7))
+    q = np.empty((n, T, model.nq))
+    pn = np.empty((n, nhum, T, 3))
+    rn = np.empty((n, nhum, T, 3))
+    for j, sd in enumerate(seeds):
+        q[j], pn[j], rn[j] = _draw_stream(model, np.random.default_rng(int(sd)), T, nhum, pos_noise, rot_noise)
+    xpos, xquat = fk_numpy(model, q)                                   # [n, T, nb, 3 / 4]
+    tp = xpos[:, :, body] + np.moveaxis(pn, 1, 2)                        # [n, T, nhum, 3]
+    tq = quat_mul(xquat[:, :, body], rotvec_quat(np.moveaxis(rn, 1, 2)))
+    # invert offset_human_data: q_h = q_t * conj(q_off); p_scaled = p_t - R(q_t) off
+    human[..., 3:] = quat_mul(tq, np.broadcast_to(qoc, tq.shape))
+    ps = tp - quat_rotate(tq, np.broadcast_to(off, tp.shape))
+    # invert scale_human_data
+    raw_root = ps[:, :, root_i] / scale[root_i]
+    raw = (ps - ps[:, :, root_i:root_i + 1]) / scale[None, None, :, None] + raw_root[:, :, None]
+    raw[:, :, root_i] = raw_root
+    human[..., :3] = raw
+    return human, q
+
+
+def make_streams_ids(model: RobotModel, tt: TaskTables, ids, T: int, seed: int = 0, pos_noise: float = 0.01,
+                     rot_noise_deg: float = 2.0, return_truth: bool = False, chunk: int = 1024, workers: int = 1):
+    """The streams ``ids`` of the batch that :func:`make_streams` generates for ``seed`` (stream i uses seed
+    ``seed + i``, whatever the set it is generated in: a rank's shard holds exactly the streams of the whole batch).
+    The random draws run per stream, the arithmetic (FK, inverse preprocessing) over ``chunk`` streams at a time;
+    ``workers`` > 1 spreads the chunks over forked processes (call before the GPU is initialised)."""
+    ids = np.asarray(ids, dtype=np.int64)
+    S = len(ids)
+    rot_noise = np.deg2rad(rot_noise_deg)
+    jobs = [(model, tt, seed + ids[s0:s0 + chunk], T, pos_noise, rot_noise) for s0 in range(0, S, chunk)]
+    if workers > 1 and len(jobs) > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+            parts = pool.map(_make_chunk, jobs)
+    else:
+        parts = [_make_chunk(j) for j in jobs]
+    human = np.concatenate([p[0] for p in parts]) if parts else np.zeros((0, T, len(tt.human_names), 7))
     q0 = np.broadcast_to(model.qpos0, (S, model.nq)).copy()
     if return_truth:
+        truth = np.concatenate([p[1] for p in parts]) if parts else np.zeros((0, T, model.nq))
         return human, q0, truth
     return human, q0
+
+
+def make_streams(model: RobotModel, tt: TaskTables, S: int, T: int, seed: int = 0,
+                 pos_noise: float = 0.01, rot_noise_deg: float = 2.0, return_truth: bool = False, chunk: int = 1024,
+                 workers: int = 1):
+    """Synthetic batch: human f64[S,T,nhuman,7], q0 f64[S,nq] (stream s uses seed ``seed + s``)."""
+    return make_streams_ids(model, tt, np.arange(S), T, seed, pos_noise, rot_noise_deg, return_truth, chunk, workers)
 
 
 def streams_to_dicts(tt: TaskTables, human_stream: np.ndarray):

@@ -30,6 +30,7 @@ extern "C" {
 #define GMR_ERR_ARG (-1)     /* bad argument / bad blob                                   */
 #define GMR_ERR_HIP (-2)     /* a HIP runtime call failed                                  */
 #define GMR_ERR_NO_DEVICE (-3)
+#define GMR_ERR_COMM (-4)    /* RCCL / bootstrap failure                                   */
 
 /* retarget flags */
 #define GMR_FLAG_OFFSET_TO_GROUND 1 /* retarget(human_data, offset_to_ground=True), motion_retarget.py:139 */
@@ -152,6 +153,30 @@ int gmr_smplx_align_dev(gmr_smplx_t* h, int N, int jstride, const float* d_full_
                         int Nout, const double* d_target_time, double* d_out, void* stream);
 int gmr_smplx_align(gmr_smplx_t* h, int N, int jstride, const float* full_pose, const float* joints, int Nout,
                     const double* target_time, double* out);
+
+/* ---- multi-GPU: one rank per GPU, ONE broadcast, no per-step collective ------------ */
+/* The reference parallelises over files with mp.Pool on one CPU (scripts/smplx_to_robot_dataset.py:241-242); here
+ * streams shard over the ranks of one node and the only data that crosses ranks is the packed robot model + task set.
+ * RCCL is opened at run time (dlopen of librccl.so; GMR_RCCL_LIBRARY overrides); no PyTorch involved. */
+typedef struct gmr_comm gmr_comm_t;
+/* Rank 0 creates the ncclUniqueId and serves it to the peers over a TCP socket at master_addr:port (the launcher's
+ * MASTER_ADDR and a port derived from MASTER_PORT), then every rank joins the communicator.  Call after
+ * gmr_set_device(local_rank). */
+int gmr_comm_create(int rank, int world, const char* master_addr, int port, gmr_comm_t** out);
+int gmr_comm_destroy(gmr_comm_t* comm);
+int gmr_comm_rank(const gmr_comm_t* comm);
+int gmr_comm_world(const gmr_comm_t* comm);
+/* `gmr_broadcast_model` of SURVEY.md section 8(b): `bytes` host bytes (gmr_model_t + gmr_taskset_t, 24 KB) of rank
+ * `root` into the same buffer on every rank (H2D, ncclBroadcast over xGMI, D2H, synchronised). */
+int gmr_comm_broadcast(gmr_comm_t* comm, void* buf, size_t bytes, int root);
+int gmr_comm_broadcast_dev(gmr_comm_t* comm, void* d_buf, size_t bytes, int root, void* stream);
+/* job-level plumbing of the drivers (not in the data path): device-synchronising barrier, timing reductions */
+int gmr_comm_barrier(gmr_comm_t* comm);
+int gmr_comm_allreduce_max(gmr_comm_t* comm, double* inout, int n);
+int gmr_comm_allreduce_sum(gmr_comm_t* comm, double* inout, int n);
+int gmr_comm_allgather(gmr_comm_t* comm, const double* in, double* out /* [world][n] */, int n);
+/* the bootstrap alone (plain TCP, no GPU): rank 0 hands `bytes` bytes to every peer */
+int gmr_bootstrap_exchange(int rank, int world, const char* addr, int port, void* payload, size_t bytes, double timeout_s);
 
 #ifdef __cplusplus
 }
