@@ -181,3 +181,201 @@ def retarget_single_clip(retargeter: GeneralMotionRetargeting, frames: Sequence,
     seq = frames[1:] if skip_first_frame else frames
     qpos = retargeter.retarget_clip(seq)
     return motion_dict(fps, qpos[:, :3].copy(), qpos[:, [4, 5, 6, 3]].copy(), qpos[:, 7:].copy(), None, None)
+
+
+# ----------------------------------------------------------------------------------------------
+# the dataset drivers with the reference's FILE semantics
+#   python -m general_motion_retargeting_amd.dataset --source smplx|bvh --src_folder ... --tgt_folder ... --robot ...
+# (scripts/smplx_to_robot_dataset.py:171-242, scripts/bvh_to_robot_dataset.py:16-157): same folder walk, same
+# skip-if-exists / --override rule, same exclusion lists, one pkl per input -- but the files of a batch share ONE IK
+# launch (and one FK launch per clip) instead of one process per file.
+# ----------------------------------------------------------------------------------------------
+EXCLUDE_FILE_CONTENT = ["BMLrub", "EKUT", "crawl", "_lie", "upstairs", "downstairs"]    # smplx_to_robot_dataset.py:218
+
+
+def natural_key(name: str):
+    """Sort key of ``natsort.natsorted`` (default algorithm: runs of digits compare as unsigned integers)."""
+    import re
+    parts = re.split(r"(\d+)", name)
+    return [int(p) if p.isdigit() else p for p in parts if p != ""]
+
+
+def _natsorted(names):
+    try:                                   # the reference uses natsort; not installed here -> same order from natural_key
+        from natsort import natsorted
+        return natsorted(names)
+    except ImportError:
+        def key(n):
+            return [(0, p, "") if isinstance(p, int) else (1, 0, p) for p in natural_key(n)]
+        return sorted(names, key=key)
+
+
+def load_hard_motions(paths) -> List[str]:
+    """Names listed in the ``assets/hard_motions/*.txt`` reports (``Motion: <name>.pkl, Difficulty: ...``;
+    smplx_to_robot_dataset.py:196-205)."""
+    import os
+    out = []
+    for p in paths:
+        if not os.path.exists(p):
+            continue
+        with open(p, "r") as f:
+            for line in f:
+                if "Motion:" not in line:
+                    continue
+                motion_path = line.split(":")[1].strip()
+                out.append(motion_path.split(",")[0].strip().split(".")[0])
+    return out
+
+
+def list_smplx_jobs(src_folder: str, tgt_folder: str, override: bool = False, hard_motions: Sequence[str] = (),
+                    exclude: Sequence[str] = tuple(EXCLUDE_FILE_CONTENT)):
+    """(source file, target pkl) pairs in the reference's order and with its filters (:208-228): natsorted walk,
+    ``*_stagei.npz`` skipped, ``.pkl`` / ``.npz`` accepted, existing targets skipped unless ``override``, hard and
+    infeasible motions removed."""
+    import os
+    jobs = []
+    for dirpath, _, filenames in os.walk(src_folder):
+        for filename in _natsorted(filenames):
+            if filename.endswith("_stagei.npz"):
+                continue
+            if filename.endswith((".pkl", ".npz")):
+                src = os.path.join(dirpath, filename)
+                tgt = src.replace(src_folder, tgt_folder).replace(".npz", ".pkl")
+                if not os.path.exists(tgt) or override:
+                    jobs.append((src, tgt))
+    hard = set(hard_motions)
+    kept = []
+    for src, tgt in jobs:
+        motion_name = src.split("/")[-1].split(".")[0]
+        if motion_name in hard or any(c in motion_name for c in exclude):
+            continue
+        kept.append((src, tgt))
+    return jobs, kept
+
+
+def list_bvh_jobs(src_folder: str, tgt_folder: str, override: bool = False, verbose: bool = True):
+    """(bvh file, target pkl) pairs of ``bvh_to_robot_dataset.py:60-73``: sorted walk, ``.bvh`` only, existing targets
+    skipped (with the script's message) unless ``override``."""
+    import os
+    jobs = []
+    for dirpath, _, filenames in os.walk(src_folder):
+        for filename in sorted(filenames):
+            if not filename.endswith(".bvh"):
+                continue
+            src = os.path.join(dirpath, filename)
+            tgt = src.replace(src_folder, tgt_folder).replace(".bvh", ".pkl")
+            if os.path.exists(tgt) and not override:
+                if verbose:
+                    print(f"Skipping {src} because {tgt} exists")
+                continue
+            jobs.append((src, tgt))
+    return jobs
+
+
+def _dump(tgt: str, motion: Dict, key_order: Sequence[str]) -> None:
+    import os
+    import pickle
+    os.makedirs(os.path.dirname(tgt) or ".", exist_ok=True)
+    with open(tgt, "wb") as f:
+        pickle.dump({k: motion[k] for k in key_order}, f)
+
+
+SMPLX_KEYS = ("fps", "root_pos", "root_rot", "dof_pos", "local_body_pos", "link_body_list")      # :134-141
+BVH_KEYS = ("root_pos", "root_rot", "dof_pos", "local_body_pos", "fps", "link_body_list")        # bvh script :141-148
+
+
+def run_smplx_dataset(src_folder: str, tgt_folder: str, robot: str, smplx_folder: str, override: bool = False,
+                      hard_motion_files: Sequence[str] = (), batch_files: int = 256, retarget=None, verbose: bool = True) -> int:
+    """``smplx_to_robot_dataset.py:main`` with ``batch_files`` files per IK launch.  ``retarget`` defaults to
+    :func:`retarget_smplx_files` (tests inject a stand-in).  Returns the number of pkl files written."""
+    retarget = retarget or retarget_smplx_files
+    all_jobs, jobs = list_smplx_jobs(src_folder, tgt_folder, override, load_hard_motions(hard_motion_files))
+    if verbose:
+        print("full args_list:", len(all_jobs))
+        print("new args_list:", len(jobs))
+        print(f"Total number of files to process: {len(jobs)}")
+    done = 0
+    for b0 in range(0, len(jobs), max(batch_files, 1)):
+        batch = jobs[b0:b0 + max(batch_files, 1)]
+        motions = retarget([s for s, _ in batch], smplx_folder, robot)
+        for (src, tgt), md in zip(batch, motions):
+            if md is None:                      # the file failed to load: printed and skipped like :62-76
+                continue
+            _dump(tgt, md, SMPLX_KEYS)
+            done += 1
+            if verbose:
+                print(f"Processed {done}/{len(jobs)}: {tgt}")
+    if verbose:
+        print("Done. Saved to ", tgt_folder)
+    return done
+
+
+def run_bvh_dataset(src_folder: str, tgt_folder: str, robot: str, override: bool = False, batch_files: int = 128,
+                    retarget=None, verbose: bool = True) -> int:
+    """``bvh_to_robot_dataset.py`` with ``batch_files`` files per IK launch (LAFAN1: all 77 clips in one)."""
+    retarget = retarget or _retarget_bvh_skipping_errors
+    jobs = list_bvh_jobs(src_folder, tgt_folder, override, verbose)
+    done = 0
+    for b0 in range(0, len(jobs), max(batch_files, 1)):
+        batch = jobs[b0:b0 + max(batch_files, 1)]
+        motions = retarget([s for s, _ in batch], robot)
+        for (src, tgt), md in zip(batch, motions):
+            if md is None:
+                continue
+            _dump(tgt, md, BVH_KEYS)
+            done += 1
+    if verbose:
+        print("Done. saved to ", tgt_folder)
+    return done
+
+
+def _retarget_bvh_skipping_errors(bvh_files: Sequence[str], tgt_robot: str) -> List[Optional[Dict]]:
+    """:func:`retarget_bvh_files` with the script's print-and-skip for files that fail to load (:77-82)."""
+    from .utils.lafan1 import load_lafan1_packed
+    gmr = GeneralMotionRetargeting("bvh", tgt_robot, actual_human_height=1.75)
+    ok, clips = [], []
+    for i, f in enumerate(bvh_files):
+        try:
+            clips.append(load_lafan1_packed(f, gmr.human_body_names)[0])
+            ok.append(i)
+        except Exception as e:  # noqa: BLE001 - mirrors the script
+            print(f"Error loading {f}: {e}")
+    out: List[Optional[Dict]] = [None] * len(bvh_files)
+    if clips:
+        res = retarget_clips("bvh", tgt_robot, clips, [30] * len(clips), actual_human_height=1.75,
+                             height_adjust=False, root_origin_offset=False)
+        for i, md in zip(ok, res):
+            out[i] = md
+    return out
+
+
+def main(argv=None) -> int:
+    import argparse
+    import pathlib
+    ap = argparse.ArgumentParser(description="Retarget a folder of SMPL-X (AMASS) or BVH (LAFAN1) motions to a robot: "
+                                             "the reference's dataset scripts on the MI355X kernels")
+    ap.add_argument("--source", choices=["smplx", "bvh"], default="smplx")
+    ap.add_argument("--robot", default="unitree_g1")
+    ap.add_argument("--src_folder", type=str, required=True)
+    ap.add_argument("--tgt_folder", type=str, required=True)
+    ap.add_argument("--override", default=False, action="store_true")
+    ap.add_argument("--num_cpus", default=4, type=int, help="accepted for compatibility; files share GPU launches instead")
+    ap.add_argument("--target_fps", default=30, type=int, help="accepted for compatibility (the BVH script ignores it too)")
+    ap.add_argument("--smplx_folder", type=str, default=None, help="SMPL-X body models (default: <assets>/body_models)")
+    ap.add_argument("--hard_motions", nargs="*", default=None, help="difficulty reports (default: <assets>/hard_motions/{0,1}.txt)")
+    ap.add_argument("--batch_files", type=int, default=256, help="files per IK launch")
+    a = ap.parse_args(argv)
+    if a.source == "bvh":
+        run_bvh_dataset(a.src_folder, a.tgt_folder, a.robot, a.override, a.batch_files)
+        return 0
+    from .params import ASSET_ROOT
+    assets = pathlib.Path(ASSET_ROOT)
+    smplx_folder = a.smplx_folder or str(assets / "body_models")
+    hard = a.hard_motions if a.hard_motions is not None else [str(assets / "hard_motions" / "0.txt"),
+                                                                str(assets / "hard_motions" / "1.txt")]
+    run_smplx_dataset(a.src_folder, a.tgt_folder, a.robot, smplx_folder, a.override, hard, a.batch_files)
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

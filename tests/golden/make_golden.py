@@ -12,6 +12,9 @@ is importable in the build container:
   CPU torch for the 7 robots it can parse: parsed tree arrays and ``forward_kinematics`` outputs
   for seeded random inputs.  This pins rows H8-H9.
 
+* G-FKAUX -- the remaining public methods of ``KinematicsModel`` (``dof_to_rot``, ``rot_to_dof``,
+  ``convert_local_rot_to_global``, ``forward_kinematics(fitted_shape=...)``, :172-246) for two robots.
+
 * G-BVH  -- the reference's LAFAN1 loader (``utils/lafan1.py`` + ``utils/lafan_vendor``, NumPy/SciPy
   only) on ``tests/golden/synthetic.bvh`` (a 22-joint, 12-frame BVH authored by this repository).
   This pins the "next" row N2.
@@ -193,6 +196,47 @@ def make_fk():
 
 
 
+def make_fk_aux():
+    """G-FKAUX: the other public methods of the reference's ``KinematicsModel`` (kinematics_model.py:172-246):
+    ``dof_to_rot``, ``rot_to_dof``, ``convert_local_rot_to_global`` and ``forward_kinematics(fitted_shape=...)``,
+    on CPU torch for two robots.  Pins those methods of row H9."""
+    import torch
+    params = _load_ref_module("params")
+    km = _load_ref_module("kinematics_model")
+    out = {}
+    for i, robot in enumerate(["unitree_g1", "booster_t1"]):
+        model = km.KinematicsModel(str(params.ROBOT_XML_DICT[robot]), device="cpu")
+        rng = np.random.default_rng(2500 + i)
+        B = 6
+        lo, hi = model.get_dof_limits()
+        lo, hi = lo.numpy(), hi.numpy()
+        dof = (lo + (hi - lo) * rng.uniform(size=(B, model.num_dof))).astype(np.float32)
+        jr = model.dof_to_rot(torch.from_numpy(dof))                       # [B, nb-1, 4] xyzw
+        out[f"{robot}__dof"] = dof
+        out[f"{robot}__joint_rot"] = jr.numpy()
+        out[f"{robot}__dof_back"] = model.rot_to_dof(jr).numpy()
+        # joints pushed beyond their limits are clamped by rot_to_dof
+        wide = (dof + rng.normal(0.0, 1.0, size=dof.shape)).astype(np.float32)
+        out[f"{robot}__dof_wide"] = wide
+        out[f"{robot}__dof_wide_back"] = model.rot_to_dof(model.dof_to_rot(torch.from_numpy(wide))).numpy()
+        rq = rng.normal(size=(B, 1, 4))
+        root = (rq / np.linalg.norm(rq, axis=-1, keepdims=True)).astype(np.float32)
+        local = np.concatenate([root, jr.numpy()], axis=1)                 # [B, nb, 4]: row 0 the root rotation
+        out[f"{robot}__local_rot"] = local
+        out[f"{robot}__global_rot"] = model.convert_local_rot_to_global(torch.from_numpy(local)).numpy()
+        shape = (1.0 + 0.2 * rng.uniform(-1, 1, size=(model.num_joint, 3))).astype(np.float32)
+        root_pos = rng.normal(size=(B, 3)).astype(np.float32)
+        bp, br = model.forward_kinematics(torch.from_numpy(root_pos), torch.from_numpy(root[:, 0]), torch.from_numpy(dof),
+                                          fitted_shape=torch.from_numpy(shape))
+        out[f"{robot}__fitted_shape"] = shape
+        out[f"{robot}__root_pos"] = root_pos
+        out[f"{robot}__root_rot"] = root[:, 0]
+        out[f"{robot}__fitted_body_pos"] = bp.numpy()
+        out[f"{robot}__fitted_body_rot"] = br.numpy()
+    np.savez_compressed(OUT / "g_fk_aux.npz", **out)
+    print("g_fk_aux.npz:", len(out), "arrays")
+
+
 def make_bvh():
     """G-BVH: the reference's LAFAN1 loader (utils/lafan1.py + lafan_vendor, NumPy/SciPy only) on the
     small synthetic BVH authored by this repository (tests/golden/synthetic.bvh)."""
@@ -270,7 +314,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "smplx":
         make_smplx()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "fk_aux":
+        make_fk_aux()
+        sys.exit(0)
     make_pre()
     make_fk()
+    make_fk_aux()
     make_bvh()
     make_smplx()

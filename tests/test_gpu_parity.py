@@ -299,6 +299,23 @@ def test_shim_offset_to_ground(hip, oracle, g1):
     assert abs(min(feet) - 0.1) < 1e-12
 
 
+def test_kinematics_model_fitted_shape_matches_reference_golden(hip):
+    """forward_kinematics(fitted_shape=...) (reference kinematics_model.py:213-246, :224): the FK kernel on a tree whose
+    local translations are scaled per body, against the reference's own outputs."""
+    import os
+    from conftest import GOLDEN
+    from general_motion_retargeting_amd import KinematicsModel, ROBOT_XML_DICT
+    G = np.load(os.path.join(GOLDEN, "g_fk_aux.npz"))
+    for robot in ("unitree_g1", "booster_t1"):
+        km = KinematicsModel(ROBOT_XML_DICT[robot])
+        bp, br = km.forward_kinematics(G[f"{robot}__root_pos"], G[f"{robot}__root_rot"], G[f"{robot}__dof"],
+                                       fitted_shape=G[f"{robot}__fitted_shape"])
+        assert np.abs(bp - G[f"{robot}__fitted_body_pos"]).max() <= 5e-6
+        assert np.abs(br - G[f"{robot}__fitted_body_rot"]).max() <= 5e-6
+        bp0, _ = km.forward_kinematics(G[f"{robot}__root_pos"], G[f"{robot}__root_rot"], G[f"{robot}__dof"])
+        assert np.abs(bp0 - bp).max() > 1e-3                                # the plain handle is untouched and differs
+
+
 def test_kinematics_model_numpy_and_torch_paths(hip, oracle):
     import os
     from conftest import GOLDEN

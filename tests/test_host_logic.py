@@ -1,5 +1,7 @@
 """Host-side logic that needs no GPU: packing of human_data dicts, error conventions, LPT
 sharding, the dataset post-processing (with the FK supplied by the oracle), synthetic generator."""
+import os
+
 import numpy as np
 import pytest
 
@@ -188,3 +190,72 @@ def test_synthetic_generator_is_seeded_and_invertible(oracle, g1):
         assert min(np.abs(tgt[i, 3:] - xquat[b]).max(), np.abs(tgt[i, 3:] + xquat[b]).max()) < 1e-12
     lo, hi = g1.model.range_lo, g1.model.range_hi
     assert (truth[..., 7:] >= lo).all() and (truth[..., 7:] <= hi).all()
+
+
+def test_dataset_drivers_follow_the_reference_file_semantics(tmp_path, capsys):
+    """Folder walk, filters, skip-if-exists / --override, one pkl per input (scripts/smplx_to_robot_dataset.py:171-242,
+    scripts/bvh_to_robot_dataset.py:60-157); the retargeting itself is replaced by a stand-in (no GPU here)."""
+    import pickle
+    from general_motion_retargeting_amd import dataset
+    src, tgt = tmp_path / "amass", tmp_path / "out"
+    files = ["A/walk_10_stageii.npz", "A/walk_2_stageii.npz", "A/walk_2_stagei.npz", "A/notes.txt", "B/BMLrub_jump.npz",
+             "B/crawl_1.npz", "B/run_1.pkl", "B/hard_one_stageii.npz", "B/broken.npz", "C/sub/upstairs_3.npz"]
+    for f in files:
+        (src / f).parent.mkdir(parents=True, exist_ok=True)
+        (src / f).write_bytes(b"x")
+    hard = tmp_path / "0.txt"
+    hard.write_text("Motions with difficulty > 5:\nMotion: hard_one_stageii.pkl, Difficulty: 14.07\nsomething else\n")
+    assert dataset.load_hard_motions([str(hard), str(tmp_path / "missing.txt")]) == ["hard_one_stageii"]
+    calls = []
+
+    def fake_retarget(paths, smplx_folder, robot):
+        calls.append(list(paths))
+        out = []
+        for p in paths:
+            if "broken" in p:
+                out.append(None)                                  # a file that failed to load: printed + skipped
+                continue
+            out.append({"fps": 30.0, "root_pos": np.zeros((2, 3)), "root_rot": np.zeros((2, 4)), "dof_pos": np.zeros((2, 29)),
+                        "local_body_pos": np.zeros((2, 38, 3), np.float32), "link_body_list": ["pelvis"], "extra": 1})
+        return out
+
+    n = dataset.run_smplx_dataset(str(src), str(tgt), "unitree_g1", "models", False, [str(hard)], batch_files=2,
+                                  retarget=fake_retarget)
+    got = sorted(str(p.relative_to(tgt)) for p in tgt.rglob("*.pkl"))
+    assert got == ["A/walk_10_stageii.pkl", "A/walk_2_stageii.pkl", "B/run_1.pkl"] and n == 3
+    flat = [os.path.relpath(p, src) for c in calls for p in c]
+    assert all(len(c) <= 2 for c in calls)                        # files grouped into launches of <= batch_files
+    a_files = [f for f in flat if f.startswith("A/")]
+    assert a_files == ["A/walk_2_stageii.npz", "A/walk_10_stageii.npz"]   # natsorted, *_stagei.npz and non-motion files skipped
+    assert not any(x in f for f in flat for x in ("BMLrub", "crawl", "upstairs", "hard_one", "stagei.npz"))
+    with open(tgt / "B" / "run_1.pkl", "rb") as f:
+        md = pickle.load(f)
+    assert list(md) == ["fps", "root_pos", "root_rot", "dof_pos", "local_body_pos", "link_body_list"]
+    out = capsys.readouterr().out
+    assert "full args_list: 8" in out and "new args_list: 4" in out and "Processed 3/4" in out
+    # second run: everything that exists is skipped; --override redoes it
+    calls.clear()
+    dataset.run_smplx_dataset(str(src), str(tgt), "unitree_g1", "models", False, [str(hard)], retarget=fake_retarget)
+    assert [os.path.relpath(p, src) for c in calls for p in c] == ["B/broken.npz"]
+    calls.clear()
+    dataset.run_smplx_dataset(str(src), str(tgt), "unitree_g1", "models", True, [str(hard)], retarget=fake_retarget)
+    assert len([p for c in calls for p in c]) == 4
+    # BVH driver: sorted walk, .bvh only, skip message, the BVH script's key order
+    bsrc, btgt = tmp_path / "lafan", tmp_path / "lafan_out"
+    for f in ["walk1_subject1.bvh", "aiming1_subject1.bvh", "readme.md", "sub/run2_subject4.bvh"]:
+        (bsrc / f).parent.mkdir(parents=True, exist_ok=True)
+        (bsrc / f).write_bytes(b"x")
+    (btgt).mkdir()
+    (btgt / "walk1_subject1.pkl").write_bytes(b"old")
+    seen = []
+
+    def fake_bvh(paths, robot):
+        seen.extend(paths)
+        return [{"fps": 30, "root_pos": np.zeros((1, 3)), "root_rot": np.zeros((1, 4)), "dof_pos": np.zeros((1, 29)),
+                 "local_body_pos": np.zeros((1, 38, 3), np.float32), "link_body_list": ["pelvis"]} for _ in paths]
+
+    assert dataset.run_bvh_dataset(str(bsrc), str(btgt), "unitree_g1", retarget=fake_bvh) == 2
+    assert [os.path.relpath(p, bsrc) for p in seen] == ["aiming1_subject1.bvh", "sub/run2_subject4.bvh"]
+    assert "Skipping" in capsys.readouterr().out and (btgt / "walk1_subject1.pkl").read_bytes() == b"old"
+    with open(btgt / "sub" / "run2_subject4.pkl", "rb") as f:
+        assert list(pickle.load(f)) == ["root_pos", "root_rot", "dof_pos", "local_body_pos", "fps", "link_body_list"]
