@@ -29,9 +29,9 @@ extern "C" hipError_t gmr_launch_ik_wide(const char*, const gmr::WideLayout*, co
                                          const double*, const int32_t*, int, double*, int32_t*, int32_t*, double*, double*,
                                          hipStream_t, unsigned long long*);
 extern "C" hipError_t gmr_ik_wide_attributes(int* num_regs, int* lds_bytes, int* max_waves_per_cu);
-extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree*, int, int, int, const float*, const float*, const float*,
+extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree*, const gmr::FkTree*, int, const float*, const float*, const float*,
                                           float*, float*, float*, float*, hipStream_t);
-extern "C" int gmr_fk_blocks(int nbody, int B);
+extern "C" int gmr_fk_blocks(int B);
 
 // up to this many streams a launch uses the 4-wave (main + 3 helpers) shape; measured crossover on MI355X
 // (tools/shape_sweep.py, G1): S=256 1.04M vs 0.93M frames/s, S=384 1.24M vs 1.40M (NW=4 vs NW=1): the switch
@@ -420,6 +420,7 @@ int gmr_fk_create(int nbody, const int32_t* parent, const float* local_t, const 
   for (int b = 0; b < nbody; b++) {
     if (dof_idx[b] >= ndof) { delete k; return fail(GMR_ERR_ARG, "dof_idx[%d] out of range", b); }
     t.dof_idx[b] = dof_idx[b];
+    if (dof_idx[b] >= 0) t.dof_body[dof_idx[b]] = (short)b;
     t.depth[b] = (short)depth[b];
     int c = b;
     for (int d = depth[b]; d >= 0; d--) { t.chain[b * maxd + d] = (short)c; c = parent[c]; }
@@ -428,6 +429,15 @@ int gmr_fk_create(int nbody, const int32_t* parent, const float* local_t, const 
     if (an < 1e-9) an = 1e-9;
     for (int a = 0; a < 3; a++) { t.local_t[3 * b + a] = local_t[3 * b + a]; t.axis[3 * b + a] = axis[3 * b + a] / an; }
     for (int a = 0; a < 4; a++) t.local_r[4 * b + a] = local_r[4 * b + a];
+  }
+  for (int b = 0; b < nbody; b++) {
+    gmr::FkBodyRec& r = t.rec[b];
+    for (int a = 0; a < 3; a++) { r.t[a] = t.local_t[3 * b + a]; r.axis[a] = t.axis[3 * b + a]; }
+    for (int a = 0; a < 4; a++) r.r[a] = t.local_r[4 * b + a];
+    r.dof_idx = t.dof_idx[b];
+    r.pad = 0;
+    r.meta = (t.dof_idx[b] >= 0 ? 1u : 0u) | ((uint32_t)(t.load_slot[b] + 1) << 8) | ((uint32_t)(t.save_slot[b] + 1) << 16) |
+             ((uint32_t)t.parent[b] << 24);
   }
   hipError_t e;
   if ((e = hipMalloc((void**)&k->d_tree, sizeof(gmr::FkTree))) != hipSuccess ||
@@ -455,7 +465,7 @@ int gmr_fk_batch_dev(gmr_fk_t* k, int B, const float* d_root_pos, const float* d
   if (B == 0) return GMR_OK;
   if (!d_root_pos || !d_root_rot || !d_body_pos || (k->tree.ndof > 0 && !d_dof)) return fail(GMR_ERR_ARG, "null device buffer");
   if (d_min_z) {
-    int blocks = gmr_fk_blocks(k->tree.nbody, B);
+    int blocks = gmr_fk_blocks(B);
     if (blocks > k->min_part_cap) {  // grows only; not graph-capturable on the first call of a size
       if (k->d_min_part) (void)hipFree(k->d_min_part);
       k->d_min_part = nullptr;
@@ -463,7 +473,7 @@ int gmr_fk_batch_dev(gmr_fk_t* k, int B, const float* d_root_pos, const float* d
       k->min_part_cap = blocks;
     }
   }
-  HIP_TRY(gmr_launch_fk_batch(k->d_tree, k->tree.nbody, k->tree.nslot, B, d_root_pos, d_root_rot, d_dof, d_body_pos,
+  HIP_TRY(gmr_launch_fk_batch(k->d_tree, &k->tree, B, d_root_pos, d_root_rot, d_dof, d_body_pos,
                               d_body_rot, k->d_min_part, d_min_z, (hipStream_t)stream));
   return GMR_OK;
 }

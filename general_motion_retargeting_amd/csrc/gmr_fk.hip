@@ -52,6 +52,25 @@ __device__ __forceinline__ void qrot_xyzw(f4 q, float vx, float vy, float vz, fl
   oz = vz * s + cz * q.w * 2.0f + q.z * d * 2.0f;
 }
 
+// sin and cos of a joint half angle (|x| of a few radians): Cody-Waite reduction by pi/2 in three pieces, the Cephes
+// single-precision kernels on [-pi/4, pi/4] (~1 ulp).  28 instructions instead of the 125 of the library call (which
+// carries a large-argument path); explicit fmaf, so `fp contract(off)` does not change it.
+__device__ __forceinline__ void sincosf_small(float x, float* sn, float* cs) {
+  const float k = rintf(x * 0.636619772367581343f);
+  float r = fmaf(-k, 1.5703125f, x);
+  r = fmaf(-k, 4.837512969970703125e-4f, r);
+  r = fmaf(-k, 7.54978995489188216e-8f, r);
+  const float z = r * r;
+  const float ps = fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f);
+  const float pc = fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f);
+  const float s = fmaf(r * z, ps, r);
+  const float c = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+  const int q = (int)k;
+  const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+  *sn = (q & 2) ? -ss : ss;
+  *cs = ((q + 1) & 2) ? -cc : cc;
+}
+
 constexpr int FK_BLOCK = 64;  // one wave per block
 
 template <bool STAGED>
@@ -81,6 +100,18 @@ __global__ __launch_bounds__(FK_BLOCK) void fk_batch_kernel(const FkTree* __rest
   float zmin = INFINITY;
   float cpx, cpy, cpz;   // transform of the body visited last (the parent of a first child)
   f4 crot;
+  if (STAGED && ndof > 0) {
+    // Park dof d of this lane's frame in its staging row at the slot of the body it drives: the walk reads it there
+    // right before it overwrites the slot with that body's position.  (Read per body during the walk, a lane's 116-B
+    // row shares no line with its neighbours': 64 lines per load and 41 KB of lines per CU in flight between two uses
+    // -> the vector L1 thrashes, 12x the L2 reads, 42 % of the wave's cycles waiting: profiles/r02_fk_*.)
+    // Every lane reads ITS row, all loads issued back to back (independent: one trip to L2, each line fetched once
+    // while its 29 users are in flight), and parks the values in its own staging row -- no cross-lane traffic.
+    const float* drow0 = dof + fc * ndof;
+    float* orow = outb + tid * row;
+#pragma unroll 8
+    for (int d = 0; d < ndof; d++) orow[3 * tree->dof_body[d]] = drow0[d];
+  }
   {
     float px = root_pos[fc * 3], py = root_pos[fc * 3 + 1], pz = root_pos[fc * 3 + 2];
     f4 rot = {root_rot[fc * 4], root_rot[fc * 4 + 1], root_rot[fc * 4 + 2], root_rot[fc * 4 + 3]};
@@ -103,25 +134,40 @@ __global__ __launch_bounds__(FK_BLOCK) void fk_batch_kernel(const FkTree* __rest
     }
   }
   const float* drow = dof + fc * ndof;
+  FkBodyRec nxt = tree->rec[nb > 1 ? 1 : 0];
+  float ang_nxt = STAGED ? (outb + tid * row)[3] : 0.0f;     // parked joint angle of body 1 (garbage if it has no joint: unused)
   for (int j = 1; j < nb; j++) {
-    // wave-uniform tree data (scalar loads)
-    const int src = tree->load_slot[j], dst = tree->save_slot[j];
-    const int di = tree->dof_idx[j];
-    const float tx = tree->local_t[3 * j], ty = tree->local_t[3 * j + 1], tz = tree->local_t[3 * j + 2];
-    f4 lr = {tree->local_r[4 * j], tree->local_r[4 * j + 1], tree->local_r[4 * j + 2], tree->local_r[4 * j + 3]};
+    // wave-uniform tree data: ONE 64-byte scalar load per body, issued one body ahead; so is the parked joint angle
+    const FkBodyRec cur = nxt;
+    nxt = tree->rec[j + 1 < nb ? j + 1 : j];
+    const float ang = ang_nxt;
+    if (STAGED) ang_nxt = (outb + tid * row)[3 * (j + 1 < nb ? j + 1 : j)];
+    const int src = (int)((cur.meta >> 8) & 255u) - 1, dst = (int)((cur.meta >> 16) & 255u) - 1;
+    const float tx = cur.t[0], ty = cur.t[1], tz = cur.t[2];
+    f4 lr = {cur.r[0], cur.r[1], cur.r[2], cur.r[3]};
     f4 cr = lr;
-    if (di >= 0) {
+    if (cur.meta & 1u) {
       // dof_to_rot: sin/cos of the float32 half angle; products and the normalisation in float64;
       // rounded to float32 on assignment (kinematics_model.py:21-36, torch_utils.py:353-359).
-      // tree->axis holds normalize(axis) (float64, computed once on the host).
-      float th = drow[di] / 2.0f;
+      // the record's axis is normalize(axis) (float64, computed once on the host).
+      float th = (STAGED ? ang : drow[cur.dof_idx]) / 2.0f;
       float sf, cf;
+#ifdef GMR_FK_LIBM_SINCOS
       sincosf(th, &sf, &cf);
+#else
+      sincosf_small(th, &sf, &cf);
+#endif
       double s = (double)sf, c = (double)cf;
-      double qx = tree->axis[3 * j] * s, qy = tree->axis[3 * j + 1] * s, qz = tree->axis[3 * j + 2] * s, qw = c;
-      // quat_unit in float64: x / |q|.  |q| is 1 to float32 rounding, so x * rsqrt(|q|^2) rounds to the
-      // same float32 as x / sqrt(|q|^2) (they differ by <= 2 ulp of float64)
+      double qx = cur.axis[0] * s, qy = cur.axis[1] * s, qz = cur.axis[2] * s, qw = c;
+      // quat_unit in float64: x / |q|.  |q|^2 = 1 + e with |e| ~ 1e-7 (float32 sin / cos of one angle, a unit axis), so
+      // 1 / |q| = 1 - e/2 + 3 e^2 / 8 to 1e-21: the quotient differs from x / sqrt(|q|^2) by < 1 ulp of float64 and
+      // rounds to the same float32 (measured bit-equal with the rsqrt form on 2^20 random frames, tools/fk_bitcheck.py)
+#ifdef GMR_FK_RSQRT_NORM
       double rn = rsqrt(fmax(qx * qx + qy * qy + qz * qz + qw * qw, 1e-18));
+#else
+      const double e = fma(qx, qx, fma(qy, qy, fma(qz, qz, fma(qw, qw, -1.0))));
+      const double rn = fma(e, fma(e, 0.375, -0.5), 1.0);
+#endif
       f4 jr = {(float)(qx * rn), (float)(qy * rn), (float)(qz * rn), (float)(qw * rn)};
       cr = qmul_xyzw(lr, jr);
     }  // no joint: r_j * (0,0,0,1) == r_j exactly
@@ -129,7 +175,7 @@ __global__ __launch_bounds__(FK_BLOCK) void fk_batch_kernel(const FkTree* __rest
     f4 prot = crot;
     if (src >= 0) {   // wave-uniform: this body is not the first child of the body before it
       if (STAGED) {
-        const int pj = tree->parent[j];
+        const int pj = (int)(cur.meta >> 24);
         const float* po = outb + tid * row + 3 * pj;
         ppx = po[0]; ppy = po[1]; ppz = po[2];
         const float* par = stk + src * 4 * FK_BLOCK;
@@ -170,13 +216,28 @@ __global__ __launch_bounds__(FK_BLOCK) void fk_batch_kernel(const FkTree* __rest
     const int nfloat = (int)(nfr * row);
     float* gdst = body_pos + f0 * row;
     const int nvec = nfloat >> 2;
-    for (int i = tid; i < nvec; i += FK_BLOCK)
-      reinterpret_cast<float4*>(gdst)[i] = reinterpret_cast<const float4*>(outb)[i];
+    {
+      // four independent LDS reads in flight per trip (a read -> wait -> store loop costs a full LDS round trip per 16 B)
+      const float4* sv = reinterpret_cast<const float4*>(outb);
+      float4* dv = reinterpret_cast<float4*>(gdst);
+      int i = tid;
+      for (; i + 3 * FK_BLOCK < nvec; i += 4 * FK_BLOCK) {
+        const float4 a0 = sv[i], a1 = sv[i + FK_BLOCK], a2 = sv[i + 2 * FK_BLOCK], a3 = sv[i + 3 * FK_BLOCK];
+        dv[i] = a0; dv[i + FK_BLOCK] = a1; dv[i + 2 * FK_BLOCK] = a2; dv[i + 3 * FK_BLOCK] = a3;
+      }
+      for (; i < nvec; i += FK_BLOCK) dv[i] = sv[i];
+    }
     for (int i = (nvec << 2) + tid; i < nfloat; i += FK_BLOCK) gdst[i] = outb[i];
     if (body_rot) {
       float4* rdst = reinterpret_cast<float4*>(body_rot + f0 * rrow);
       const int nrv = (int)(nfr * nb);
-      for (int i = tid; i < nrv; i += FK_BLOCK) rdst[i] = reinterpret_cast<const float4*>(outr)[i];
+      const float4* sv = reinterpret_cast<const float4*>(outr);
+      int i = tid;
+      for (; i + 3 * FK_BLOCK < nrv; i += 4 * FK_BLOCK) {
+        const float4 a0 = sv[i], a1 = sv[i + FK_BLOCK], a2 = sv[i + 2 * FK_BLOCK], a3 = sv[i + 3 * FK_BLOCK];
+        rdst[i] = a0; rdst[i + FK_BLOCK] = a1; rdst[i + 2 * FK_BLOCK] = a2; rdst[i + 3 * FK_BLOCK] = a3;
+      }
+      for (; i < nrv; i += FK_BLOCK) rdst[i] = sv[i];
     }
   }
   if (min_part) {
@@ -203,39 +264,50 @@ __global__ __launch_bounds__(256) void min_reduce_kernel(const float* __restrict
 
 }  // namespace gmr
 
-extern "C" int gmr_fk_blocks(int nbody, int B) {
-  (void)nbody;
-  return (B + gmr::FK_BLOCK - 1) / gmr::FK_BLOCK;
+// blocks of a launch over B frames: one wave per 64 frames; also the size of the min-z partials
+extern "C" int gmr_fk_blocks(int B) { return (B + gmr::FK_BLOCK - 1) / gmr::FK_BLOCK; }
+
+// > 64 KB of dynamic LDS needs an opt-in per kernel and per DEVICE: done once for every device this process uses
+static hipError_t fk_opt_in_large_lds() {
+  static unsigned long long done_mask = 0;       // bit = device ordinal (benign if two threads race: the call is idempotent)
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 64 && ((done_mask >> dev) & 1ull)) return hipSuccess;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(gmr::fk_batch_kernel<true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+  if (e == hipSuccess && dev < 64) __atomic_fetch_or(&done_mask, 1ull << dev, __ATOMIC_RELAXED);
+  return e;
 }
 
-extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree* d_tree, int nbody, int nslot, int B,
+extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree* d_tree, const gmr::FkTree* h_tree, int B,
                                           const float* d_root_pos, const float* d_root_rot, const float* d_dof,
                                           float* d_body_pos, float* d_body_rot, float* d_min_part, float* d_min_z,
                                           hipStream_t stream) {
   if (B <= 0) return hipSuccess;
-  int blocks = gmr_fk_blocks(nbody, B);
+  const int nbody = h_tree->nbody, nslot = h_tree->nslot;
+  const int blocks = gmr_fk_blocks(B);
   size_t smem = (size_t)nslot * 7 * gmr::FK_BLOCK * sizeof(float);   // direct variant: parked (pos, rot)
   // 16-B aligned destinations: LDS-staged, fully coalesced output
   // (the block strides FK_BLOCK * nbody * 12 B and * 16 B are multiples of 16)
   const size_t stage_bytes = (size_t)gmr::FK_BLOCK * nbody * (d_body_rot ? 7 : 3) * sizeof(float);
-  const bool staged = (reinterpret_cast<uintptr_t>(d_body_pos) & 15u) == 0 &&
-                      (reinterpret_cast<uintptr_t>(d_body_rot) & 15u) == 0 && stage_bytes <= 160 * 1024 - 8192;
+  bool staged = (reinterpret_cast<uintptr_t>(d_body_pos) & 15u) == 0 && (reinterpret_cast<uintptr_t>(d_body_rot) & 15u) == 0 &&
+                stage_bytes <= 160 * 1024 - 8192;
   if (staged) {
     // staged variant: parent positions are re-read from the staging area; only rotations are parked
     smem = (size_t)nslot * 4 * gmr::FK_BLOCK * sizeof(float) + stage_bytes;
-    static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in once per process
-    if (!attr_set) {
-      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(gmr::fk_batch_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-      if (ea != hipSuccess) return ea;
-      attr_set = true;
+    if (smem > 64 * 1024 && fk_opt_in_large_lds() != hipSuccess) {   // no opt-in on this device: the direct variant still works
+      (void)hipGetLastError();
+      staged = false;
+      smem = (size_t)nslot * 7 * gmr::FK_BLOCK * sizeof(float);
     }
+  }
+  if (staged)
     hipLaunchKernelGGL(gmr::fk_batch_kernel<true>, dim3(blocks), dim3(gmr::FK_BLOCK), smem, stream, d_tree, B,
                        d_root_pos, d_root_rot, d_dof, d_body_pos, d_body_rot, d_min_z ? d_min_part : nullptr);
-  } else {
+  else
     hipLaunchKernelGGL(gmr::fk_batch_kernel<false>, dim3(blocks), dim3(gmr::FK_BLOCK), smem, stream, d_tree, B,
                        d_root_pos, d_root_rot, d_dof, d_body_pos, d_body_rot, d_min_z ? d_min_part : nullptr);
-  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (d_min_z) {
@@ -244,4 +316,3 @@ extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree* d_tree, int nbody, 
   }
   return e;
 }
-

@@ -475,7 +475,7 @@ __device__ __forceinline__ void hacc_phase_g(const LT& L, double* sm, int stage,
 // lanes) while this wave gathers c and the bounds; three workgroup barriers per assembly.
 template <int NW, class LT>
 __device__ __forceinline__ void build_qp_main(const LT& L, double* sm, int stage, const StageTabs& tb,
-                                              const short* hinge_body, const short* limited, int* ctl,
+                                              const short* hinge_body, const short* limited, int* ctl, int& epoch,
                                               double damping, double lm_damping, double limit_gain, int lane,
                                               Prof& pr) {
   double mu = jlog_phase<NW>(L, sm, stage, lm_damping, lane, pr);
@@ -494,7 +494,8 @@ __device__ __forceinline__ void build_qp_main(const LT& L, double* sm, int stage
     PROF_END(pr, PH_HACC);
   } else {
     PROF_BEGIN(pr);
-    if (lane == 0) { ctl[0] = CMD_BUILD; ctl[1] = stage; (sm + L.o.scal)[0] = diag; }
+    if (lane == 0) { int* c = ctl + 2 * (epoch & 1); c[0] = CMD_BUILD; c[1] = stage; (sm + L.o.scal)[0] = diag; }
+    epoch++;
     __syncthreads();                      // B1: helpers see the command; M / we and the body Jacobians are final
     pairs_from_jbody(L, sm, stage, tb, lane, 64 * NW);
     __syncthreads();                      // B2: all Jacobian columns written
@@ -514,13 +515,13 @@ __device__ __forceinline__ void helper_loop(const LT& L, double* sm, const uint3
                                             const short* hinge_body, const int* ctl, int wave, int lane,
                                             Prof& hp) {
   TreeState bs = {0ull, 0ull};            // bound sets of the QP (identical in every wavefront)
-  for (;;) {
+  for (int epoch = 0;; epoch++) {         // command n sits in mailbox slot n & 1 (see the main wavefront)
     PROF_BEGIN(hp);
     __syncthreads();                      // B1 (or the EXIT barrier)
     PROF_END(hp, PH_PRE);                 // (helper stamps reuse the slots: PRE = idle at B1)
-    const int cmd = ctl[0];
+    const int cmd = ctl[2 * (epoch & 1)];
     if (cmd == CMD_EXIT) return;
-    const int stage = ctl[1];
+    const int stage = ctl[2 * (epoch & 1) + 1];
     StageTabs tb = {si + L.o.i_task_body[stage], si + L.o.i_task_human[stage], si + L.o.i_pair_task[stage],
                     si + L.o.i_pair_dof[stage], si + L.o.i_pair_index[stage], sw + L.w_items[stage]};
     if (cmd == CMD_JBODY) {               // the main wavefront is evaluating the residuals meanwhile
@@ -856,6 +857,10 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
   int qp_state = 0;     // this lane's bound state of the previous solve (QP warm start)
   TreeState tree_state = {0ull, 0ull};
   int h_stage = -1;     // stage whose sparsity pattern H currently holds
+  // Commands to the helper wavefronts go through a two-slot mailbox, alternating per command: a helper reads the slot
+  // of command n right after the barrier that publishes it, the main wavefront writes command n + 1 into the OTHER
+  // slot, so no write ever races a read (both sides count commands: `epoch`).
+  int epoch = 0;
   // first frame's raw targets
   double r0 = 0.0, r1 = 0.0;
   if (Ts > 0) {
@@ -893,13 +898,14 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
         // every residual evaluation is preceded by a kick of the helpers: they turn the FK state into the body
         // Jacobians of this stage's (task, dof) pairs while this wavefront evaluates residuals and Jl^-1
         if (NW > 1) {
-          if (lane == 0) { ctl[0] = CMD_JBODY; ctl[1] = stage; }
+          if (lane == 0) { int* c = ctl + 2 * (epoch & 1); c[0] = CMD_JBODY; c[1] = stage; }
+          epoch++;
           __syncthreads();
         }
         double curr = errors_wave<NW>(L, sm, tb.task_body, tb.task_human, K, lane, pr);
         int nsol = 0, num_iter = 0;
         for (;;) {
-          build_qp_main<NW>(L, sm, stage, tb, hinge_body, limited, ctl, prm[0], prm[1], prm[3], lane, pr);
+          build_qp_main<NW>(L, sm, stage, tb, hinge_body, limited, ctl, epoch, prm[0], prm[1], prm[3], lane, pr);
           PROF_COUNT(pr, PH_NSOLVE);
           int rc;
           if (NW > 1) {   // the 4-wavefront shape is only launched for robots that decompose (gmr_abi.hip)
@@ -917,7 +923,8 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
           integrate_wave<NW>(L, sm, prm[5], lane, pr);
           fk_wave<NW>(L, sm, hop, depth, body_hinge, lane, pr);
           if (NW > 1) {
-            if (lane == 0) { ctl[0] = CMD_JBODY; ctl[1] = stage; }
+            if (lane == 0) { int* c = ctl + 2 * (epoch & 1); c[0] = CMD_JBODY; c[1] = stage; }
+            epoch++;
             __syncthreads();
           }
           double next = errors_wave<NW>(L, sm, tb.task_body, tb.task_human, K, lane, pr);
@@ -946,7 +953,7 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
   }
   if (lane == 0) status[s] = stat;
   if (NW > 1) {                           // release the helper waves
-    if (lane == 0) ctl[0] = CMD_EXIT;
+    if (lane == 0) ctl[2 * (epoch & 1)] = CMD_EXIT;
     __syncthreads();
   }
 #ifdef GMR_IK_PROFILE

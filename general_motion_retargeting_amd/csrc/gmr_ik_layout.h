@@ -101,7 +101,7 @@ constexpr IkOffsets ik_offsets(int nvp, int nw) {
   }
   L.n_short = (i + 7) / 8 * 8;
   int w = 0;
-  L.w_ctl = w; w += 2;
+  L.w_ctl = w; w += 4;                             // two mailbox slots {command, stage}, alternating per command
   L.w_tr_mask = w; w += 16;
   L.w_tr_cnt = w; w += 4;
   if (w % 4) w += 4 - w % 4;                       // the schedule starts 16-byte aligned
