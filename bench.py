@@ -12,8 +12,11 @@ N = 1 (default)  `value` = BASELINE.json configs[1]: the 10k-frame batch, S=100 
                  box's host cores.  Beside it, `strong_1m`: the 1M-frame batch of the multi-GPU leg on this one GPU.
 N > 1            (launched by `python -m torch.distributed.run`, one rank per GPU; the launcher only provides
                  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*: the ranks talk through the library's own RCCL communicator,
-                 no PyTorch)  `value` = the 1M-frame synthetic batch north_star names -- S=65536 streams x T=16
-                 frames, the same seeds for every N -- LPT-sharded over the N GPUs after ONE RCCL broadcast of the packed
+                 no PyTorch)  `value` = the 1M-frame synthetic batch north_star names -- S=131072 streams x T=8
+                 frames, the same seeds for every N (wide enough that one of 8 GPUs still holds 16 384 streams: measured
+                 on one GPU, 16 384 streams run at 0.91 of the rate of 131 072, 8 192 x 16 only at 0.83 of 65 536 x 16:
+                 the tail of the longest streams, no communication involved) -- LPT-sharded over the N GPUs after ONE
+                 RCCL broadcast of the packed
                  robot model + task set; no per-step collective ("scaling": "strong").  Rank 0 then runs the whole
                  batch alone on its GPU in the same run: `value_1gpu`, `efficiency` = value / (N * value_1gpu).
                  `weak_leg`: configs[1]'s S=100 x T=100 per rank (its makespan is the slowest of 100 N streams: the
@@ -85,8 +88,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=100, help="configs[1] leg: streams per GPU")
     ap.add_argument("--frames", type=int, default=100, help="configs[1] leg: frames per stream")
-    ap.add_argument("--strong-streams", type=int, default=65536, help="1M-frame leg: streams in the whole batch")
-    ap.add_argument("--strong-frames", type=int, default=16, help="1M-frame leg: frames per stream")
+    ap.add_argument("--strong-streams", type=int, default=131072, help="1M-frame leg: streams in the whole batch")
+    ap.add_argument("--strong-frames", type=int, default=8, help="1M-frame leg: frames per stream")
     ap.add_argument("--no-strong", action="store_true", help="skip the 1M-frame leg")
     ap.add_argument("--robot", default="unitree_g1")
     ap.add_argument("--src", default="smplx")
@@ -112,6 +115,8 @@ def main():
     lens = np.full(SS, ST, dtype=np.int64)
     my_ids = sharding.lpt_partition(lens, world)[rank] if strong else []
     workers = min(16, len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else 4
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+        workers = 1         # a profiler's preloaded tool library owns the GPU already: do not fork worker processes under it
     if strong:
         if rank == 0:       # rank 0 holds the whole batch (the one-GPU reference leg); its shard is a view of it
             h_all, q_all = synth.make_streams(model, tt, SS, ST, seed=strong_seed, workers=workers)

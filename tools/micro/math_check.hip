@@ -31,6 +31,11 @@ __global__ void k_sc(int n, const double* in, double* out) {
   sincos_small(in[i], &s, &c);
   out[3 * i] = s; out[3 * i + 1] = c; out[3 * i + 2] = fast_rcp(1.0 + fabs(in[i]));
 }
+__global__ void k_at(int n, const double* in, double* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = atan2_q1(in[2 * i], in[2 * i + 1]);
+}
 
 static double urand() { return rand() / (double)RAND_MAX; }
 
@@ -84,5 +89,20 @@ int main() {
     dr = fmax(dr, fabs(o[3 * i + 2] * (1.0 + fabs(x[i])) - 1.0));
   }
   printf("sincos_small vs libm on [-300, 300]: max |ds| = %.3e, max |dc| = %.3e; fast_rcp max rel err = %.3e\n", ds, dc, dr);
-  return (de < 1e-12 && dj < 1e-10 && ds < 4e-16 && dc < 4e-16 && nan == 0) ? 0 : 1;
+  // atan2_q1 vs host libm on the first quadrant: unit vectors (sin, cos of a half angle), tiny and huge ratios
+  std::vector<double> yx(2 * (size_t)n), at(n);
+  for (int i = 0; i < n; i++) {
+    double h = (i & 1) ? urand() * 1.5707963267948966 : exp(log(1e-12) + urand() * (log(1.5707963) - log(1e-12)));
+    if (i % 101 == 0) h = 1.5707963267948966 - 1e-9 * urand();
+    yx[2 * i] = sin(h); yx[2 * i + 1] = cos(h);
+    if (i % 7 == 0) { yx[2 * i] *= 0.37; yx[2 * i + 1] *= 0.37; }      // the scale must not matter
+  }
+  yx[0] = 0.0; yx[1] = 1.0; yx[2] = 1.0; yx[3] = 0.0; yx[4] = 1.0; yx[5] = 1.0;
+  hipMemcpy(d_in, yx.data(), 2 * (size_t)n * 8, hipMemcpyHostToDevice);
+  k_at<<<n / 256, 256>>>(n, d_in, d_a);
+  hipMemcpy(at.data(), d_a, n * 8, hipMemcpyDeviceToHost);
+  double dat = 0;
+  for (int i = 0; i < n; i++) { double ref = atan2(yx[2 * i], yx[2 * i + 1]); dat = fmax(dat, fabs(at[i] - ref) / fmax(ref, 1e-300)); }
+  printf("atan2_q1 vs libm: max relative error = %.3e\n", dat);
+  return (de < 1e-12 && dj < 1e-10 && ds < 4e-16 && dc < 4e-16 && dat < 1e-15 && nan == 0) ? 0 : 1;
 }
