@@ -356,28 +356,30 @@ __device__ __forceinline__ double dpp_row_shr(double v, double fill, int n) {   
   }
   return r.d;
 }
-// value of the neighbouring lane (lane ^ 1): DPP quad_perm [1, 0, 3, 2]
+// value of the neighbouring lane (lane ^ 1): DPP quad_perm [1, 0, 3, 2] (every lane has a source: no `old` operand,
+// so no register copy in front of the DPP move)
 __device__ __forceinline__ double dpp_swap_pairs(double v) {
   union { double d; int i[2]; } a, r;
   a.d = v;
-  r.i[0] = __builtin_amdgcn_update_dpp(a.i[0], a.i[0], 0xB1, 0xf, 0xf, false);
-  r.i[1] = __builtin_amdgcn_update_dpp(a.i[1], a.i[1], 0xB1, 0xf, 0xf, false);
+  r.i[0] = __builtin_amdgcn_mov_dpp(a.i[0], 0xB1, 0xf, 0xf, true);
+  r.i[1] = __builtin_amdgcn_mov_dpp(a.i[1], 0xB1, 0xf, 0xf, true);
   return r.d;
 }
-// value of lane k of the own 16-lane row, in every lane of that row: DPP row_newbcast:k (gfx90a+); four
-// independent broadcasts per instruction pair (one per row), the result stays in a VGPR
-#define GMR_ROW_BCAST_CASE(K) case K: r.i[0] = __builtin_amdgcn_update_dpp(a.i[0], a.i[0], 0x150 + K, 0xf, 0xf, false); \
-                                      r.i[1] = __builtin_amdgcn_update_dpp(a.i[1], a.i[1], 0x150 + K, 0xf, 0xf, false); break;
+// value of lane k of the own 16-lane row, in every lane of that row: DPP row_newbcast:k.  gfx90a+ executes this ONE
+// control on 64-bit operands (v_mov_b64_dpp), so a double is broadcast by a single instruction: four independent
+// broadcasts (one per row), the result stays in a VGPR.  (As two 32-bit update_dpp with a tied `old` operand it was two
+// register copies + two DPP moves: 45 % of the tree solver's vector instructions were moves.)
+#define GMR_ROW_BCAST_CASE(K) case K: y = __builtin_amdgcn_update_dpp(x, x, 0x150 + K, 0xf, 0xf, true); break;
 __device__ __forceinline__ double row_bcast_d(double v, int k) {
-  union { double d; int i[2]; } a, r;
-  a.d = v; r.d = v;
+  const long long x = __builtin_bit_cast(long long, v);
+  long long y = x;
   switch (k) {
     GMR_ROW_BCAST_CASE(0) GMR_ROW_BCAST_CASE(1) GMR_ROW_BCAST_CASE(2) GMR_ROW_BCAST_CASE(3)
     GMR_ROW_BCAST_CASE(4) GMR_ROW_BCAST_CASE(5) GMR_ROW_BCAST_CASE(6) GMR_ROW_BCAST_CASE(7)
     GMR_ROW_BCAST_CASE(8) GMR_ROW_BCAST_CASE(9) GMR_ROW_BCAST_CASE(10) GMR_ROW_BCAST_CASE(11)
     GMR_ROW_BCAST_CASE(12) GMR_ROW_BCAST_CASE(13) GMR_ROW_BCAST_CASE(14) GMR_ROW_BCAST_CASE(15)
   }
-  return r.d;
+  return __builtin_bit_cast(double, y);
 }
 #undef GMR_ROW_BCAST_CASE
 // sum of lanes 0..15 (lanes 16..63 must hold 0 or are ignored), the same value in every lane
