@@ -325,6 +325,19 @@ __device__ __forceinline__ void se3_jlinv_aux5(const double e[6], const double a
   for (int i = 0; i < 9; i++) { A.a[i] = Am.a[i]; B.a[i] = -AQA.a[i]; }
 }
 
+// The lane id as a value the optimiser cannot see through.  Every predicate on the lane id (lane < nb, lane == pivot, ...)
+// is invariant for the whole kernel, so LLVM computes each ONCE at kernel entry and keeps its 64-bit mask in an SGPR
+// pair; a fully inlined frame loop has more than a hundred of them, they spill to VGPR lanes (v_writelane) and every
+// use pays two v_readlane -- a fifth of the vector instructions of the latency kernel's solve loop.  A phase that
+// starts from fresh_lane() recomputes the few predicates it needs (one v_cmp each) and lets them die at its end.
+// GMR_NO_FRESH_LANE restores the hoisted form (A/B builds).
+__device__ __forceinline__ int fresh_lane(int lane) {
+#ifndef GMR_NO_FRESH_LANE
+  asm volatile("" : "+v"(lane));
+#endif
+  return lane;
+}
+
 // wave64 butterfly reductions (deterministic, every lane gets the result)
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

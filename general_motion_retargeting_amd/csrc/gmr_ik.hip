@@ -85,6 +85,7 @@ namespace gmr {
 template <int NW, class LT>
 __device__ __forceinline__ void fk_wave(const LT& L, double* sm, const short* hop, const short* depth,
                                         const short* body_hinge, int lane, Prof& pr) {
+  lane = fresh_lane(lane);
   PROF_BEGIN(pr);
   const int nb = L.nb;
   double* q = sm + L.o.q;
@@ -152,6 +153,7 @@ __device__ __forceinline__ void fk_wave(const LT& L, double* sm, const short* ho
 template <int NW, class LT>
 __device__ __forceinline__ double errors_wave(const LT& L, double* sm, const short* task_body,
                                               const short* task_human, int K, int lane, Prof& pr) {
+  lane = fresh_lane(lane);
   PROF_BEGIN(pr);
   double ss = 0.0;
   if (lane < K) {
@@ -187,6 +189,7 @@ struct StageTabs {
 template <int NW, class LT>
 __device__ __forceinline__ double jlog_phase(const LT& L, double* sm, int stage, double lm_damping, int lane,
                                              Prof& pr) {
+  lane = fresh_lane(lane);
   PROF_BEGIN(pr);
   const int K = L.K[stage];
   const double* wpos = sm + L.o.wpos[stage];
@@ -339,6 +342,7 @@ __device__ __forceinline__ void pairs_from_jbody(const LT& L, double* sm, int st
 template <class LT>
 __device__ __forceinline__ void cvec_phase(const LT& L, double* sm, int stage, const StageTabs& tb,
                                            const short* limited, double limit_gain, int lane) {
+  lane = fresh_lane(lane);
   const int K = L.K[stage], nv = L.nv;
   const double* cpart = sm + L.o.cpart;
   if (lane < nv) {
@@ -711,6 +715,7 @@ __device__ __forceinline__ void hinge_sincos(const LT& L, double* sm, int lane) 
 // ---------------------------------------------------------------------------------------------
 template <int NW, class LT>
 __device__ __forceinline__ void integrate_wave(const LT& L, double* sm, double dt, int lane, Prof& pr) {
+  lane = fresh_lane(lane);
   PROF_BEGIN(pr);
   double* q = sm + L.o.q;
   const double* dq = sm + L.o.x;
@@ -750,6 +755,7 @@ __device__ __forceinline__ void integrate_wave(const LT& L, double* sm, double d
 template <int NW, class LT>
 __device__ __forceinline__ void preprocess_wave(const LT& L, double* sm, const short* is_foot, int human_root,
                                                 double ground_offset, int flags, int lane, Prof& pr) {
+  lane = fresh_lane(lane);
   PROF_BEGIN(pr);
   const double* raw = sm + L.o.raw;
   double* tgt = sm + L.o.tgt;

@@ -49,7 +49,16 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
   constexpr int TR_NV = TR_NL + TR_NT;             // local matrix order
   static_assert(!ROWS || TR_NV <= 16, "a limb's local matrix must fit one 16-lane row");
   const int wave = ROWS ? (lane_in >> 4) : wave_in;        // which limb this wavefront / row eliminates
-  const int lane = ROWS ? (lane_in & 15) : lane_in;        // row of the local matrix
+  const int lane0 = ROWS ? (lane_in & 15) : lane_in;       // row of the local matrix
+  // Every phase below starts from a FRESH copy of the row index (fresh_lane, gmr_device_math.h): its lane predicates
+  // (row == pivot, row > pivot, ...) are recomputed where they are used and die with the phase, instead of being
+  // computed once per kernel and parked in (spilled) SGPR pairs.
+#define TR_ROW()                                                                                   \
+  const int lane = fresh_lane(lane0);                                                              \
+  const bool is_limb = lane < TR_NL, is_trunk = lane >= TR_NL && lane < TR_NV;                     \
+  const int a = lane, t = lane - TR_NL;                                                            \
+  (void)is_limb; (void)is_trunk; (void)a; (void)t;
+  const int lane = lane0;
   static_assert(!DPPB || TR_NV <= 16, "DPP row broadcasts need the local matrix in one 16-lane row");
 #define TR_BCAST(v, k) ((ROWS || DPPB) ? row_bcast_d((v), (k)) : readlane_d((v), (k)))
 #define TR_SYNC() do { if (ROWS) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); else __syncthreads(); } while (0)
@@ -94,6 +103,9 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
     double r[TR_NV];
 #pragma unroll
     for (int m = 0; m < TR_NV; m++) r[m] = 0.0;
+    double rhs0, b;
+    {
+    TR_ROW()
 #pragma unroll
     for (int m = 0; m < TR_NL; m++) {
       const int cd = cdof[m];                                 // wave-uniform
@@ -106,7 +118,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
       r[m] = v;
     }
     // -c_i - sum over fixed j of H_ij x_j (the bound value of j from the uniform sets)
-    double rhs0 = row ? (self_fixed ? xfix : -ci) : 0.0;
+    rhs0 = row ? (self_fixed ? xfix : -ci) : 0.0;
     if (row && !self_fixed) {
       unsigned long long mm = fixedm;
       while (mm) {
@@ -115,7 +127,8 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
         rhs0 -= Hrow[j] * (((bs.lower >> j) & 1ull) ? los[j] : his[j]);
       }
     }
-    double b = is_limb ? rhs0 : 0.0;
+    b = is_limb ? rhs0 : 0.0;
+    }
     PROF_END(pr, PH_KBUILD);
     PROF_BEGIN(pr);
     // ---- (2) eliminate the limb pivots (right-looking, forward substitution merged) --------------
@@ -127,6 +140,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
     double dinv = fast_rsqrt(dp);
 #pragma unroll
     for (int p = 0; p < TR_NL; p++) {
+      const int lane = fresh_lane(lane0);                    // (lane > p), (lane == p): computed here, dead after this pivot
       bad = bad || !(dp > 0.0);
       double l = lane > p ? r[p] * dinv : 0.0;               // column p of L_l (rows > p) and of Y_l
       if (lane == p) { mydinv = dinv; r[p] = dp * dinv; } else r[p] = l;
@@ -145,6 +159,9 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
     PROF_END(pr, PH_CHOL);
     PROF_BEGIN(pr);
     // ---- (3) publish the Schur contribution; park L_l / Y_l for the transposed reads --------------
+    unsigned long long* vcur = vset + 4 * (it & 1);
+    {
+    TR_ROW()
     if (is_trunk) {
 #pragma unroll
       for (int u = 0; u < TR_NT; u++) Spart[(wave * TR_MAX_NT + t) * TR_MAX_NT + u] = r[TR_NL + u];
@@ -154,11 +171,11 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
 #pragma unroll
       for (int m = 0; m < TR_NL; m++) Lscr[lane * TR_LD + m] = r[m];
     }
-    unsigned long long* vcur = vset + 4 * (it & 1);
     if (lane == 0 && bad) atomicOr(&vcur[3], 1ull);
     TR_SYNC();                                                                               // B1
     // the other slot was last read before this barrier: clear it for the next round
     if (wave == 0 && lane < 4) vset[4 * ((it + 1) & 1) + lane] = 0ull;
+    }
     PROF_END(pr, PH_SUBST);
     PROF_BEGIN(pr);
     // ---- (4) every wavefront: trunk Schur complement, factor, solve (redundant, no exchange) -------
@@ -169,6 +186,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
 #pragma unroll
       for (int u = 0; u < TR_NT; u++) s[u] = 0.0;
       {
+        TR_ROW()
         // all loads first (clamped addresses, no branches), then the masks
         const int tt = is_trunk ? t : 0;
         double hv[TR_NT], sp[TR_NT];
@@ -196,6 +214,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
       double dinv = fast_rsqrt(dq);
 #pragma unroll
       for (int q = 0; q < TR_NT; q++) {
+        const int t = fresh_lane(lane0) - TR_NL;             // (t > q), (t == q): computed here, dead after this pivot
         tbad = tbad || !(dq > 0.0);
         double l = t > q ? s[q] * dinv : 0.0;
         if (t == q) { tdinv = dinv; s[q] = dq * dinv; } else s[q] = l;
@@ -213,18 +232,22 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
       }
       // back substitution: L^T through this wavefront's scratch (columns 8..17 of rows 8..17 are free)
       double* Tscr = Lscr + TR_NL;
-      if (is_trunk) {
-#pragma unroll
-        for (int u = 0; u < TR_NT; u++) Tscr[lane * TR_LD + u] = s[u];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       double lt[TR_NT];
+      {
+        TR_ROW()
+        if (is_trunk) {
 #pragma unroll
-      for (int q = 0; q < TR_NT; q++) lt[q] = is_trunk ? Tscr[(TR_NL + q) * TR_LD + t] : 0.0;
+          for (int u = 0; u < TR_NT; u++) Tscr[lane * TR_LD + u] = s[u];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#pragma unroll
+        for (int q = 0; q < TR_NT; q++) lt[q] = is_trunk ? Tscr[(TR_NL + q) * TR_LD + t] : 0.0;
+      }
 #pragma unroll
       for (int q = TR_NT - 1; q >= 0; q--) {
+        const int t = fresh_lane(lane0) - TR_NL;             // rows outside the trunk have t < 0 or t >= TR_NT: lt = 0 there
         const double xq = TR_BCAST(bt * tdinv, TR_NL + q);
-        bt = t == q ? xq : (is_trunk && t < q ? fma(-lt[q], xq, bt) : bt);
+        bt = t == q ? xq : (t >= 0 && t < q ? fma(-lt[q], xq, bt) : bt);
       }
     }
     PROF_END(pr, PH_RATIO);
@@ -233,20 +256,24 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
     double x = bt;                                                                     // trunk lanes
     {
       double lt[TR_NL];
-#pragma unroll
-      for (int m = 0; m < TR_NL; m++) lt[m] = is_limb ? Lscr[m * TR_LD + a] : 0.0;     // column a of L_l
       double bb = b;                                                                   // y_l (limb lanes)
+      {
+        TR_ROW()
 #pragma unroll
-      for (int u = 0; u < TR_NT; u++) {
-        const double xt = TR_BCAST(bt, TR_NL + u);
-        if (is_limb) bb = fma(-Lscr[(TR_NL + u) * TR_LD + a], xt, bb);                 // Y_l[u][a]
+        for (int m = 0; m < TR_NL; m++) lt[m] = is_limb ? Lscr[m * TR_LD + a] : 0.0;   // column a of L_l
+#pragma unroll
+        for (int u = 0; u < TR_NT; u++) {
+          const double xt = TR_BCAST(bt, TR_NL + u);
+          if (is_limb) bb = fma(-Lscr[(TR_NL + u) * TR_LD + a], xt, bb);               // Y_l[u][a]
+        }
       }
 #pragma unroll
       for (int p = TR_NL - 1; p >= 0; p--) {
+        const int lane = fresh_lane(lane0);
         const double xp = TR_BCAST(bb * mydinv, p);
         bb = lane == p ? xp : (lane < p ? fma(-lt[p], xp, bb) : bb);
       }
-      if (is_limb) x = bb;
+      if (fresh_lane(lane0) < TR_NL) x = bb;
     }
     // ---- (6) violated bounds (free set) / multipliers (fixed set): g = H x + c ---------------------
     if (fixedm != 0ull) {                                     // multipliers need the whole x
@@ -272,7 +299,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
     }
     // each violating owner lane sets its dof's bit in the round's set (LDS atomic OR: order-independent)
     if (newst != 0) atomicOr(&vcur[newst - 1], 1ull << dof);
-    if (lane == 0 && tbad) atomicOr(&vcur[3], 1ull);
+    if (fresh_lane(lane0) == 0 && tbad) atomicOr(&vcur[3], 1ull);
     TR_SYNC();                                                                               // B3
     PROF_END(pr, PH_IO);
     const unsigned long long to_lo = vcur[0], to_up = vcur[1], rel = vcur[2];
@@ -294,6 +321,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
   return GMR_STATUS_QP_MAXITER;
 #undef TR_BCAST
 #undef TR_SYNC
+#undef TR_ROW
 }
 
 }  // namespace gmr
