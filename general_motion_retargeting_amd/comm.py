@@ -120,8 +120,8 @@ class TorchComm:
         return t.cpu().numpy()
 
     def barrier(self):
-        if self.dev == "cuda":
-            from . import _lib
+        from . import _lib
+        if _lib.lib().gmr_device_count() > 0:        # the library's launches must be complete, whatever carries the barrier
             _lib.check(_lib.lib().gmr_stream_sync(None))
         self._sync()
         self.dist.barrier()
