@@ -252,6 +252,10 @@ __device__ __forceinline__ void hacc_wide(double* sm, const char* __restrict__ i
   uint2 n[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) n[k] = p[k * 64];
+  // H takes the place of the residual / -Jl^-1 / c-share scratch (all consumed by now): structural zeros and the rows
+  // of absent variables are never written by the schedule, so the block starts from zero
+  for (int i = lane; i < WD_HN; i += 64) H[i] = 0.0;
+  wsync();
   double acc = 0.0;
   for (int it = 0; it < ntrip; it += 4) {
     uint2 w[4];
@@ -297,8 +301,9 @@ __device__ __forceinline__ int solve_rows(const WideDims& D, double* sm, const c
   double* xs = sm + LD.x;
   const double* los = sm + LD.lo;
   const double* his = sm + LD.hi;
-  double* Spart = sm + LD.spart;                  // [4][NT][NT]
+  double* Spart = sm + LD.spart;                  // [4][NT (NT + 1) / 2]: lower triangles of the Schur contributions
   double* rpart = sm + LD.rpart;                  // [4][NT]
+  double* Tsh = sm + LD.tsh;                      // [NT][WD_TT]: the trunk factor, identical in all groups (benign same-value writes)
   double* xl = sm + LD.xl;                        // x by owner lane (multipliers)
   double* Lscr = sm + LD.lscr + grp * 16 * TLD;   // this group's transpose scratch
   unsigned long long* vset = reinterpret_cast<unsigned long long*>(sm + LD.vset);   // {to_lower, to_upper, release, flags} x 2
@@ -424,14 +429,15 @@ __device__ __forceinline__ int solve_rows(const WideDims& D, double* sm, const c
 #pragma unroll
           for (int ri = 0; ri < 4; ri++) {
             const int rowi = mk + 4 * ri;
-            if (rowi >= NL) Spart[(g * NT + (rowi - NL)) * NT + (mi - NL)] = -acc[g][ri];
+            if (rowi >= NL && mi <= rowi) Spart[g * WD_TRI + ((rowi - NL) * (rowi - NL + 1)) / 2 + (mi - NL)] = -acc[g][ri];
           }
       }
     }
 #else
-    if (is_trunk) {
+    if (is_trunk) {                                           // row t of the contribution: columns u <= t only are ever read
+      double* sp = Spart + grp * WD_TRI + (t * (t + 1)) / 2;
 #pragma unroll
-      for (int u = 0; u < NT; u++) Spart[(grp * NT + t) * NT + u] = r[NL + u];
+      for (int u = 0; u < NT; u++) if (u <= t) sp[u] = r[NL + u];
     }
 #endif
     unsigned long long* vcur = vset + 4 * (it & 1);
@@ -452,8 +458,8 @@ __device__ __forceinline__ int solve_rows(const WideDims& D, double* sm, const c
 #pragma unroll
         for (int u = 0; u < NT; u++) {
           hv[u] = Trow[u];
-          const double* q0 = Spart + tt * NT + u;
-          sp[u] = (q0[0] + q0[NT * NT]) + (q0[2 * NT * NT] + q0[3 * NT * NT]);
+          const double* q0 = Spart + (tt * (tt + 1)) / 2 + (u <= tt ? u : 0);       // (u > t: unused, any valid address)
+          sp[u] = (q0[0] + q0[WD_TRI]) + (q0[2 * WD_TRI] + q0[3 * WD_TRI]);
         }
         const double rp = (rpart[tt] + rpart[NT + tt]) + (rpart[2 * NT + tt] + rpart[3 * NT + tt]);
         const bool live = is_trunk && row && !self_fixed;
@@ -487,15 +493,14 @@ __device__ __forceinline__ int solve_rows(const WideDims& D, double* sm, const c
         dinv2 = dinv_next;
       }
       // back substitution: L^T through this group's scratch (columns 7..15 of rows 7..15)
-      double* Tscr = Lscr + NL;
       if (is_trunk) {
 #pragma unroll
-        for (int u = 0; u < NT; u++) Tscr[lane * TLD + u] = s[u];
+        for (int u = 0; u < NT; u++) Tsh[t * WD_TT + u] = s[u];
       }
       wsync();
       double lt[NT];
 #pragma unroll
-      for (int q = 0; q < NT; q++) lt[q] = is_trunk ? Tscr[(NL + q) * TLD + t] : 0.0;
+      for (int q = 0; q < NT; q++) lt[q] = is_trunk ? Tsh[q * WD_TT + t] : 0.0;
 #pragma unroll
       for (int q = NT - 1; q >= 0; q--) {
         const double xq = row_bcast_d(bt * tdinv, NL + q);
@@ -691,7 +696,6 @@ __global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(
   const double* hs = human + (size_t)s * T * fstride;
   int stat = GMR_STATUS_OK;
   RowState bounds = {0ull, 0ull};
-  int h_stage = -1;     // stage whose sparsity pattern H currently holds
   double r0 = 0.0, r1 = 0.0;
   if (Ts > 0) {
     if (lane < (int)fstride) r0 = hs[lane];
@@ -716,12 +720,6 @@ __global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(
         if (!(stage == 0 ? use0 : use1) || (flags & GMR_FLAG_EVAL_ONLY)) continue;
         const int K = D.K[stage];
         const uint32_t taskw = lane < K ? img_at<uint32_t>(img, IM.taski[stage])[lane] : 0u;
-        if (h_stage != stage) {
-          // structural zeros of the compact H are never written by the schedule: clear when the pattern changes
-          for (int i = lane; i < WD_HN; i += 64) (sm + LD.H)[i] = 0.0;
-          h_stage = stage;
-          wsync();
-        }
         double curr = errors_wide(sm, taskw, K, lane, pr);
         int nsol = 0, num_iter = 0;
         for (;;) {

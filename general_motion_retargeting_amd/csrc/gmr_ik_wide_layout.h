@@ -7,8 +7,9 @@
 //     per-lane loads (vector L1 / L2 hits, shared by all streams of a CU) or scalar loads;
 //   * H is stored in the block-arrowhead form the tree solver consumes (four 16 x 7 limb matrices [D_l; B_l] and
 //     the 9 x 9 trunk block: 529 instead of 36 x 37 doubles), written there directly by the assembly schedule;
-//   * the assembly scratch and the solver scratch are trimmed and share one region.
-// 22.1 KB per stream instead of 37.5 KB: 7 instead of 4 streams per CU.
+//   * the solver's input H is assembled into the space of the residual / -Jl^-1 scratch, the solver's own scratch
+//     lives where the Jacobian columns were: every byte of the assembly is reused by the solve.
+// 18.4 KB per stream instead of 37.5 KB: 8 instead of 4 streams per CU, two wavefronts on every SIMD.
 //
 // Only robots that decompose into <= 4 limbs of <= 7 dofs and a trunk of <= 9 (every shipped robot) and fit the
 // capacities below use this shape; others keep the one-wavefront kernel of gmr_ik.hip with the dense solver.
@@ -30,14 +31,21 @@ constexpr int WD_K = 16;         // tasks per stage
 constexpr int WD_P = 160;        // (task, dof) pairs per stage
 constexpr int WD_NHUM = 16;      // human bodies
 constexpr int WD_NL = 7, WD_NT = 9;          // limb / trunk rows of the tree solver
-constexpr int WD_LD = 17;                    // row stride of the solver's transpose scratch (odd)
+constexpr int WD_LD = 9;                     // row stride of the solver's limb transposes (7 columns, odd stride)
+constexpr int WD_TT = 10;                    // row stride of the trunk transpose (shared by the four row groups)
+constexpr int WD_TRI = WD_NT * (WD_NT + 1) / 2;   // a Schur contribution is read as its lower triangle only
 
 // ---- LDS (offsets in doubles) ---------------------------------------------------------------------------------
+// Three regions are live at different times and share one block:
+//   A = [e | wts | M] and C = [cpart]   residuals, weights, -Jl^-1 blocks (jlog -> column phase), column shares of c
+//   B = [Jw]                            weighted Jacobian columns (column phase -> H assembly)
+// H (the solver's input) is written by the assembly INTO A and C -- both are dead once the columns and c exist --
+// and the solver's scratch lives in B, dead once H is assembled.  Nothing of a solve survives it except x.
 struct WideLds {
   int q, hsc, xa, xaxis, tgt;                 // state
   int e, wts, M, Jw, cpart, eaux, raw, xb;    // assembly scratch (eaux aliases cpart, raw aliases M, xb aliases Jw)
-  int lscr, spart, rpart, xl;                 // solver scratch (aliases the assembly scratch)
-  int H;                                      // compact H: LM[4][16][7] then T[9][9]
+  int lscr, tsh, spart, rpart, xl;            // solver scratch (aliases Jw)
+  int H;                                      // compact H: LM[4][16][7] then T[9][9] (aliases e .. M and cpart)
   int c, x, lo, hi;
   int vset;                                   // 8 x u64: violation sets of the pivoting rounds (double-buffered)
   int n_double;
@@ -54,33 +62,36 @@ constexpr WideLds wide_lds() {
   L.xaxis = o; o += 3 * WD_NB;
   L.tgt = o; o += 7 * WD_NHUM + 1;
   if (o & 1) o++;
-  const int s0 = o;
+  // regions A and C, contiguous: H must fit them
   L.e = o; o += 6 * WD_K;
   L.wts = o; o += 2 * WD_K;
   L.M = o; o += 18 * WD_K;
   L.raw = L.M;                                // consumed by the preprocess step, before any solve
-  if (o & 1) o++;                             // Jw rows (48 B) are read as three 16-B pieces
-  L.Jw = o; o += 6 * WD_P;
-  L.xb = L.Jw;                                // FK runs between solves, when the assembly scratch is dead
   L.cpart = o; o += WD_P;
-  L.eaux = L.cpart;                           // (a, sin, cos) of the residual phase die before the columns are written
-  const int s1 = o;
-  // solver scratch in the same region (live only inside a solve)
-  int t = s0;
+  L.eaux = L.cpart;                           // (a, sin, cos, t, 1/t) of the residual phase die before the columns are written
+  L.H = L.e;
+  if (o - L.e < WD_HN + 1) o = L.e + WD_HN + 1;
+  if (o & 1) o++;                             // Jw rows (48 B) are read as three 16-B pieces
+  // region B
+  L.Jw = o; o += 6 * WD_P;
+  L.xb = L.Jw;                                // FK runs between solves, when this region is dead
+  int t = L.Jw;
   L.lscr = t; t += 4 * 16 * WD_LD;
-  L.spart = t; t += 4 * WD_NT * WD_NT;
+  L.tsh = t; t += WD_NT * WD_TT;
+  L.spart = t; t += 4 * WD_TRI;
   L.rpart = t; t += 4 * WD_NT;
   L.xl = t; t += 64;
-  o = ik_max(s1, t);
+  if (t > o) o = t;
   if (o & 1) o++;
-  L.H = o; o += WD_HN + 1;
   L.c = o; o += 36; L.x = o; o += 36; L.lo = o; o += 36; L.hi = o; o += 36;
   L.vset = o; o += 8;
   L.n_double = o;
   return L;
 }
 constexpr int WD_LDS_BYTES = wide_lds().n_double * 8;
-static_assert(7 * 18 <= 6 * WD_P && 7 * WD_NB + 1 <= 6 * WD_P, "aliases must fit");
+static_assert(7 * WD_NB + 1 <= 6 * WD_P, "the second FK buffer must fit the Jw region");
+static_assert(wide_lds().xl + 64 <= wide_lds().Jw + 6 * WD_P, "the solver scratch must fit the Jw region");
+static_assert(WD_LDS_BYTES * 8 <= 160 * 1024, "eight streams per CU");
 static_assert(7 * WD_NHUM + 1 <= 18 * WD_K, "raw frame must fit the M region");
 static_assert(5 * WD_K <= WD_P, "eaux must fit the cpart region");
 
