@@ -125,6 +125,11 @@ def main():
             h_mine, q_mine = synth.make_streams_ids(model, tt, my_ids, ST, seed=strong_seed, workers=max(1, workers // 2))
 
     # ---- device + communicator -------------------------------------------------------------------------------------
+    # No torch in this process unless a torch backend is asked for: bind the library to the SYSTEM HIP runtime, the one
+    # the system's librccl.so is linked against (with torch installed, _lib would otherwise preload torch's bundled copy
+    # so that a later `import torch` shares it: two HIP runtimes in one process is what that avoids, here as there).
+    if (os.environ.get("GMR_BENCH_BACKEND") or os.environ.get("GMR_COMM_BACKEND") or "rccl").lower() == "rccl":
+        os.environ.setdefault("GMR_HIP_RUNTIME", "system")
     L = _lib.lib()
     _lib.require_gpu()
     _lib.check(L.gmr_set_device(local_rank % max(L.gmr_device_count(), 1)))

@@ -190,6 +190,15 @@ int gmr_comm_create(int rank, int world, const char* master_addr, int port, gmr_
   if (rc) return rc;
   ncclUniqueId id;
   memset(&id, 0, sizeof id);
+  // RCCL prints a start-up banner (version, host, library path) on stdout; callers own stdout (bench.py prints ONE JSON
+  // line there): send whatever RCCL prints while it initialises to stderr
+  fflush(stdout);
+  const int saved_stdout = dup(STDOUT_FILENO);
+  if (saved_stdout >= 0) dup2(STDERR_FILENO, STDOUT_FILENO);
+  struct RestoreStdout {
+    int fd;
+    ~RestoreStdout() { if (fd >= 0) { fflush(stdout); dup2(fd, STDOUT_FILENO); close(fd); } }
+  } restore{saved_stdout};
   if (rank == 0) NCCL_TRY(g_rccl.GetUniqueId(&id));
   double timeout_s = 120.0;
   if (const char* t = getenv("GMR_COMM_TIMEOUT")) timeout_s = atof(t) > 0 ? atof(t) : timeout_s;
