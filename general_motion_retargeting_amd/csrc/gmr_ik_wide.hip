@@ -203,6 +203,8 @@ __device__ __forceinline__ void pairs_wide(double* sm, const char* __restrict__ 
     }
     cpart[p] = cp;   // this column's contribution to c = sum_k (W J_k)^T (W e_k)
   }
+  if (lane < 6) Jw[6 * WD_P + lane] = 0.0;   // the row the padding items of the H schedule read
+  if (lane == 6) cpart[WD_P] = 0.0;          // and the share absent (task, dof) pairs gather
 }
 
 // (c) lane = dof: gather c; bounds of the limited hinges (mink ConfigurationLimit)
@@ -211,16 +213,16 @@ __device__ __forceinline__ void cvec_wide(const WideDims& D, double* sm, const c
   const double* cpart = sm + LD.cpart;
   if (lane < D.nv) {
     const uint32_t* ci = img_at<uint32_t>(img, IM.cidx[stage]) + lane;
-    uint32_t w[WD_K / 4];
+    uint32_t w[WD_K / 2];
 #pragma unroll
-    for (int g = 0; g < WD_K / 4; g++) w[g] = ci[64 * g];
+    for (int g = 0; g < WD_K / 2; g++) w[g] = ci[64 * g];
     const double2 lim = img_at<double2>(img, IM.lim)[lane];
     const uint32_t limited = img_at<uint32_t>(img, IM.limi)[lane];
     double cc = 0.0;
 #pragma unroll
     for (int k = 0; k < WD_K; k++) {
-      const uint32_t idx = (w[k / 4] >> (8 * (k % 4))) & 255u;
-      cc += idx != 255u ? cpart[idx] : 0.0;
+      const uint32_t off = (k & 1) ? w[k / 2] >> 16 : w[k / 2] & 0xffffu;   // byte offset; absent pairs name the zero slot
+      cc += *reinterpret_cast<const double*>(reinterpret_cast<const char*>(cpart) + off);
     }
     (sm + LD.c)[lane] = cc;
     double lo = -INFINITY, hi = INFINITY;
@@ -236,7 +238,7 @@ __device__ __forceinline__ void cvec_wide(const WideDims& D, double* sm, const c
 
 // (d) H: every lane sums the terms of the entries it owns (static schedule, streamed from the global image: the
 // same words for every stream of the CU) and stores each entry once, directly where the solver reads it
-struct dd2 { double x, y; };
+struct __attribute__((aligned(16))) dd2 { double x, y; };   // Jw rows start on 16-byte boundaries: one b128 read per piece
 __device__ __forceinline__ double dot6v(const double* a, const double* b) {
   const dd2* pa = reinterpret_cast<const dd2*>(a);
   const dd2* pb = reinterpret_cast<const dd2*>(b);
@@ -247,11 +249,13 @@ __device__ __forceinline__ double dot6v(const double* a, const double* b) {
 __device__ __forceinline__ void hacc_wide(double* sm, const char* __restrict__ img, int items_off, int ntrip, double diag,
                                           int lane) {
   double* __restrict__ H = sm + LD.H;
-  const double* __restrict__ J = sm + LD.Jw;
+  char* __restrict__ Hb = reinterpret_cast<char*>(H);
+  const char* __restrict__ Jb = reinterpret_cast<const char*>(sm + LD.Jw);
   const uint2* p = img_at<uint2>(img, items_off) + lane;
   uint2 n[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) n[k] = p[k * 64];
+  const int dof = img_at<int>(img, IM.tree)[lane];
   // H takes the place of the residual / -Jl^-1 / c-share scratch (all consumed by now): structural zeros and the rows
   // of absent variables are never written by the schedule, so the block starts from zero
   for (int i = lane; i < WD_HN; i += 64) H[i] = 0.0;
@@ -267,21 +271,22 @@ __device__ __forceinline__ void hacc_wide(double* sm, const char* __restrict__ i
     }
     double s[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      s[k] = dot6v(J + 6 * (w[k].x & 511u), J + 6 * ((w[k].x >> 9) & 511u));
-      if ((w[k].x >> 30) & 1u) s[k] = 0.0;
-    }
+    for (int k = 0; k < 4; k++)
+      s[k] = dot6v(reinterpret_cast<const double*>(Jb + (w[k].x & 0xffffu)), reinterpret_cast<const double*>(Jb + (w[k].x >> 16)));
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       acc += s[k];
-      if (w[k].y >> 31) {
-        const double v = acc + (((w[k].y >> 22) & 1u) ? diag : 0.0);
-        H[w[k].y & 2047u] = v;
-        H[(w[k].y >> 11) & 2047u] = v;
+      if ((int)w[k].y < 0) {
+        *reinterpret_cast<double*>(Hb + (w[k].y & 0x1fffu)) = acc;
+        *reinterpret_cast<double*>(Hb + ((w[k].y >> 13) & 0x1fffu)) = acc;
         acc = 0.0;
       }
     }
   }
+  // the damping term: lane 16 g + a owns the diagonal of limb variable (g, a), lanes 7..15 the trunk's
+  wsync();
+  const int r = lane & 15;
+  if (dof >= 0 && (r < WD_NL || lane < 16)) H[r < WD_NL ? 7 * lane + r : WD_HT + (WD_NT + 1) * (r - WD_NL)] += diag;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -67,13 +67,13 @@ constexpr WideLds wide_lds() {
   L.wts = o; o += 2 * WD_K;
   L.M = o; o += 18 * WD_K;
   L.raw = L.M;                                // consumed by the preprocess step, before any solve
-  L.cpart = o; o += WD_P;
+  L.cpart = o; o += WD_P + 1;                   // slot WD_P is kept zero: the share of an absent (task, dof) pair
   L.eaux = L.cpart;                           // (a, sin, cos, t, 1/t) of the residual phase die before the columns are written
   L.H = L.e;
   if (o - L.e < WD_HN + 1) o = L.e + WD_HN + 1;
   if (o & 1) o++;                             // Jw rows (48 B) are read as three 16-B pieces
   // region B
-  L.Jw = o; o += 6 * WD_P;
+  L.Jw = o; o += 6 * (WD_P + 1);                // row WD_P is kept zero: what the padding items of the schedule read
   L.xb = L.Jw;                                // FK runs between solves, when this region is dead
   int t = L.Jw;
   L.lscr = t; t += 4 * 16 * WD_LD;
@@ -105,7 +105,7 @@ struct WideImg {
   int task[2];    // f64 [WD_K][2] w_pos, w_rot ; then u32 [WD_K] body | human << 8              lane = task
   int taski[2];
   int pair[2];    // u32 [WD_P]         task | dof << 4 | task body << 10 | hinge body << 16   virtual lane = pair
-  int cidx[2];    // u8  [WD_K][64]     pair id of (task k, dof = lane) or 255, as u32 [WD_K/4][64]
+  int cidx[2];    // u16 [WD_K][64]     byte offset of the c share of (task k, dof = lane) in cpart (absent: slot WD_P), as u32 [WD_K/2][64]
   int lim;        // f64 [64][2] range lo, hi ; then u32 [64] limited                             lane = dof
   int limi;
   int tree;       // i32 [64] dof of solver lane (16 l + row) or -1
@@ -125,7 +125,7 @@ constexpr WideImg wide_img() {
     I.task[s] = o; o += wd_up16(WD_K * 2 * 8);
     I.taski[s] = o; o += wd_up16(WD_K * 4);
     I.pair[s] = o; o += wd_up16(WD_P * 4);
-    I.cidx[s] = o; o += wd_up16(WD_K * 64);
+    I.cidx[s] = o; o += wd_up16(WD_K * 64 * 2);
   }
   I.lim = o; o += wd_up16(64 * 2 * 8);
   I.limi = o; o += wd_up16(64 * 4);
@@ -147,10 +147,12 @@ struct WideLayout : WideDims {
   int image_bytes;
 };
 
-// H-assembly item (64 bit).  lo: [8:0] pair a, [17:9] pair b, [30] contributes nothing.
-// hi: [10:0] first store offset in the compact H (doubles), [21:11] second store offset (the symmetric twin, or the
-// same), [22] diagonal entry (the damping term is added), [31] last term of the entry.
-constexpr uint32_t WD_ITEM_NOP = 1u << 30;
+// H-assembly item (64 bit), everything pre-scaled to LDS byte offsets so that a slot costs two integer instructions
+// beside its six FMAs.  lo: [15:0] byte offset of Jw row a, [31:16] of row b (padding items name the zero row WD_P
+// twice).  hi: [12:0] first store offset in the compact H (bytes), [25:13] second store offset (the symmetric twin, or
+// the same), [31] last term of the entry.  The damping term of the diagonal is added by the dof lanes afterwards.
+constexpr uint32_t WD_ITEM_NOP = (48u * WD_P) | ((48u * WD_P) << 16);
+static_assert(48 * WD_P < 65536 && 8 * WD_HN < 8192, "item fields");
 
 // position of a dof in the tree decomposition
 struct WideLoc { int limb, idx; };            // limb = -1: trunk row idx
@@ -160,7 +162,7 @@ inline bool wide_fits(const gmr_model_t& m, const gmr_taskset_t& ts) {
   if (!tree.ok || tree.nt > WD_NT) return false;
   for (auto& l : tree.limb) { int n = 0; for (int d : l) n += d >= 0; if (n > WD_NL) return false; }
   if (m.nbody > WD_NB || m.nhinge > WD_NH || ts.nhuman > WD_NHUM) return false;
-  for (int s = 0; s < 2; s++) if (ts.ntask[s] > WD_K || ts.npair[s] > WD_P || ts.npair[s] > 254) return false;
+  for (int s = 0; s < 2; s++) if (ts.ntask[s] > WD_K || ts.npair[s] > WD_P) return false;
   int maxd = 1;
   for (int b = 0; b < m.nbody; b++) maxd = std::max(maxd, m.depth[b] + 1);
   return maxd <= 32;
@@ -182,7 +184,7 @@ inline bool make_wide_schedule(const gmr_model_t& m, const gmr_taskset_t& ts, st
       for (int a = 0; a < n; a++)
         for (int b = 0; b <= a; b++) {
           int da = ts.pair_dof[s][c0 + a], db = ts.pair_dof[s][c0 + b];
-          terms[(size_t)da * nv + db].push_back((uint32_t)(c0 + a) | ((uint32_t)(c0 + b) << 9));
+          terms[(size_t)da * nv + db].push_back(48u * (uint32_t)(c0 + a) | ((48u * (uint32_t)(c0 + b)) << 16));
         }
     }
     struct Ent { int da, db, w; uint32_t hi; };
@@ -190,7 +192,7 @@ inline bool make_wide_schedule(const gmr_model_t& m, const gmr_taskset_t& ts, st
     for (int da = 0; da < nv; da++)
       for (int db = 0; db <= da; db++) {
         int w = (int)terms[(size_t)da * nv + db].size();
-        if (w == 0 && da != db) continue;
+        if (w == 0) continue;                                    // the block is zero-filled before the schedule runs
         const WideLoc A = loc[da], B = loc[db];
         int o1, o2;
         if (A.limb >= 0 && B.limb >= 0) {
@@ -199,7 +201,7 @@ inline bool make_wide_schedule(const gmr_model_t& m, const gmr_taskset_t& ts, st
         } else if (A.limb >= 0) { o1 = o2 = (16 * A.limb + 7 + B.idx) * 7 + A.idx; }
         else if (B.limb >= 0) { o1 = o2 = (16 * B.limb + 7 + A.idx) * 7 + B.idx; }
         else { o1 = WD_HT + A.idx * WD_NT + B.idx; o2 = WD_HT + B.idx * WD_NT + A.idx; }
-        ents.push_back({da, db, w, (uint32_t)o1 | ((uint32_t)o2 << 11) | (da == db ? 1u << 22 : 0u)});
+        ents.push_back({da, db, w, (uint32_t)(8 * o1) | ((uint32_t)(8 * o2) << 13)});
       }
     std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.w > y.w; });
     std::vector<std::vector<Ent>> per_lane(64);
@@ -208,14 +210,13 @@ inline bool make_wide_schedule(const gmr_model_t& m, const gmr_taskset_t& ts, st
       int best = 0;
       for (int l = 1; l < 64; l++) if (load[l] < load[best]) best = l;
       per_lane[best].push_back(e);
-      load[best] += std::max(e.w, 1) + 1;
+      load[best] += e.w + 1;
     }
     int nt = 0;
     std::vector<std::vector<uint64_t>> li(64);
     for (int l = 0; l < 64; l++) {
       for (const Ent& e : per_lane[l]) {
         const auto& tt = terms[(size_t)e.da * nv + e.db];
-        if (tt.empty()) li[l].push_back(((uint64_t)(e.hi | (1u << 31)) << 32) | WD_ITEM_NOP);
         for (size_t i = 0; i < tt.size(); i++)
           li[l].push_back(((uint64_t)(e.hi | (i + 1 == tt.size() ? (1u << 31) : 0u)) << 32) | tt[i]);
       }
@@ -281,11 +282,11 @@ inline WideLayout make_wide_layout(const gmr_model_t& m, const gmr_taskset_t& ts
       U(I.pair[s])[p] = (uint32_t)k | ((uint32_t)d << 4) | ((uint32_t)ts.task_body[s][k] << 10) |
                         ((uint32_t)(d >= 6 ? m.hinge_body[d - 6] : 0) << 16);
     }
-    uint8_t* ci = reinterpret_cast<uint8_t*>(base + I.cidx[s]);       // [k / 4][lane][k % 4]
+    uint16_t* ci = reinterpret_cast<uint16_t*>(base + I.cidx[s]);     // [k / 2][lane][k % 2]
     for (int k = 0; k < WD_K; k++)
       for (int d = 0; d < 64; d++) {
         int v = (k < ts.ntask[s] && d < m.nv) ? ts.pair_index[s][k][d] : -1;
-        ci[((k / 4) * 64 + d) * 4 + (k % 4)] = (uint8_t)(v >= 0 ? v : 255);
+        ci[((k / 2) * 64 + d) * 2 + (k % 2)] = (uint16_t)(8 * (v >= 0 ? v : WD_P));
       }
     std::memcpy(base + L.items[s], items[s].data(), items[s].size() * 8);
   }
