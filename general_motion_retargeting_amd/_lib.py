@@ -47,6 +47,7 @@ _SIGS = {
     "gmr_solver_destroy": (C.c_int, [C.c_void_p]),
     "gmr_solver_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gmr_solver_set_waves": (C.c_int, [C.c_void_p, C.c_int]),
+    "gmr_solver_set_dispatch": (C.c_int, [C.c_void_p, C.c_int]),
     "gmr_retarget_lds_bytes": (C.c_int, [C.c_void_p]),
     "gmr_retarget_streams_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -255,6 +256,10 @@ class Solver:
     def set_waves(self, waves_per_stream: int) -> None:
         """0 = automatic, 1 = one wavefront per stream, 4 = main + 3 helper wavefronts per stream."""
         check(lib().gmr_solver_set_waves(self.handle, int(waves_per_stream)))
+
+    def set_dispatch(self, frames_per_item: int) -> None:
+        """Many-stream launches: > 0 = device-side FIFO of (stream, frames_per_item frames) items, 0 = one workgroup per stream."""
+        check(lib().gmr_solver_set_dispatch(self.handle, int(frames_per_item)))
 
     @property
     def lds_bytes(self) -> int:

@@ -27,7 +27,10 @@ extern "C" hipError_t gmr_launch_ik_streams(const uint4*, const gmr::IkLayout*, 
 extern "C" hipError_t gmr_ik_set_max_smem(int nvp, int nw, int tree_small, int bytes);
 extern "C" hipError_t gmr_launch_ik_wide(const char*, const gmr::WideLayout*, const gmr::IkParams*, int, int, const double*,
                                          const double*, const int32_t*, int, double*, int32_t*, int32_t*, double*, double*,
-                                         hipStream_t, unsigned long long*);
+                                         hipStream_t, unsigned long long*, void*);
+extern "C" void* gmr_ik_wide_pool_create();
+extern "C" void gmr_ik_wide_pool_destroy(void*);
+extern "C" void gmr_ik_wide_pool_set_chunk(void*, int);
 extern "C" hipError_t gmr_ik_wide_attributes(int* num_regs, int* lds_bytes, int* max_waves_per_cu);
 extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree*, const gmr::FkTree*, int, const float*, const float*, const float*,
                                           float*, float*, float*, float*, hipStream_t);
@@ -68,6 +71,7 @@ struct gmr_solver {
   uint4* d_image = nullptr;      // host-built LDS image of the constants (gmr_ik_layout.h)
   gmr::WideLayout wide;          // throughput shape (gmr_ik_wide.hip): ok = 0 when the robot does not fit it
   char* d_wide = nullptr;        // its global image of the constants
+  void* wide_pool = nullptr;     // queue workspaces of its queued dispatch mode (one per HIP stream)
   char* ws = nullptr;            // grow-only device workspace of the host-buffer entry point
   size_t ws_bytes = 0;
   char* pin = nullptr;           // pinned host staging for small calls (one H2D + one D2H per call)
@@ -233,12 +237,14 @@ int gmr_solver_create(const gmr_model_t* model, const gmr_taskset_t* taskset, gm
     if (s->wide.ok) {
       if ((e = hipMalloc((void**)&s->d_wide, img.size())) == hipSuccess)
         e = hipMemcpy(s->d_wide, img.data(), img.size(), hipMemcpyHostToDevice);
+      if (e == hipSuccess) s->wide_pool = gmr_ik_wide_pool_create();
     }
   }
   if (e != hipSuccess) {
     if (s->d_image) (void)hipFree(s->d_image);
     if (s->d_image4) (void)hipFree(s->d_image4);
     if (s->d_wide) (void)hipFree(s->d_wide);
+    gmr_ik_wide_pool_destroy(s->wide_pool);
     delete s;
     return fail(GMR_ERR_HIP, "gmr_solver_create: %s", hipGetErrorString(e));
   }
@@ -251,6 +257,7 @@ int gmr_solver_destroy(gmr_solver_t* s) {
   (void)hipFree(s->d_image);
   (void)hipFree(s->d_image4);
   if (s->d_wide) (void)hipFree(s->d_wide);
+  gmr_ik_wide_pool_destroy(s->wide_pool);
   if (s->ws) (void)hipFree(s->ws);
   if (s->pin) (void)hipHostFree(s->pin);
   delete s;
@@ -273,6 +280,13 @@ int gmr_solver_set_waves(gmr_solver_t* s, int waves_per_stream) {
   return GMR_OK;
 }
 
+int gmr_solver_set_dispatch(gmr_solver_t* s, int frames_per_item) {
+  if (!s) return fail(GMR_ERR_ARG, "null solver");
+  if (frames_per_item < 0) return fail(GMR_ERR_ARG, "frames_per_item must be >= 0");
+  if (s->wide_pool) gmr_ik_wide_pool_set_chunk(s->wide_pool, frames_per_item);
+  return GMR_OK;
+}
+
 int gmr_retarget_lds_bytes(const gmr_solver_t* s) { return s ? s->layout4.smem_bytes : 0; }
 
 int gmr_retarget_streams_dev(gmr_solver_t* s, int S, int T, const double* d_q0, const double* d_human,
@@ -287,7 +301,7 @@ int gmr_retarget_streams_dev(gmr_solver_t* s, int S, int T, const double* d_q0, 
   const bool wide = s->layout4.tree_ok && (s->force_waves ? s->force_waves == 4 : S <= GMR_HELPER_MAX_STREAMS);
   if (!wide && s->wide.ok)     // throughput shape: two resident wavefronts per SIMD (gmr_ik_wide.hip)
     HIP_TRY(gmr_launch_ik_wide(s->d_wide, &s->wide, &s->params, S, T, d_q0, d_human, d_len, flags, d_q_out, d_nsolve,
-                               d_status, d_tgt_out, d_err_out, (hipStream_t)stream, nullptr));
+                               d_status, d_tgt_out, d_err_out, (hipStream_t)stream, nullptr, s->wide_pool));
   else
     HIP_TRY(gmr_launch_ik_streams(wide ? s->d_image4 : s->d_image, wide ? &s->layout4 : &s->layout, &s->params, S, T,
                                   d_q0, d_human, d_len, flags, d_q_out, d_nsolve, d_status, d_tgt_out, d_err_out,
@@ -302,7 +316,7 @@ int gmr_retarget_streams_prof(gmr_solver_t* s, int S, int T, const double* d_q0,
   const bool wide = s->layout4.tree_ok && (s->force_waves ? s->force_waves == 4 : S <= GMR_HELPER_MAX_STREAMS);
   if (!wide && s->wide.ok)
     HIP_TRY(gmr_launch_ik_wide(s->d_wide, &s->wide, &s->params, S, T, d_q0, d_human, nullptr, flags, d_q_out, d_nsolve,
-                               d_status, nullptr, nullptr, nullptr, d_prof));
+                               d_status, nullptr, nullptr, nullptr, d_prof, nullptr));
   else
     HIP_TRY(gmr_launch_ik_streams(wide ? s->d_image4 : s->d_image, wide ? &s->layout4 : &s->layout, &s->params, S, T,
                                   d_q0, d_human, nullptr, flags, d_q_out, d_nsolve, d_status, nullptr, nullptr, nullptr, d_prof));

@@ -47,7 +47,8 @@ __device__ __forceinline__ const T* img_at(const char* img, int byte_off) {
 // ---------------------------------------------------------------------------------------------
 // FK: mj_kinematics semantics (App. A.3) by pointer jumping, lane = body (see fk_wave in gmr_ik.hip)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fk_wide(const WideDims& D, double* sm, const char* __restrict__ img, int lane, Prof& pr) {
+__device__ __forceinline__ void fk_wide(const WideDims& D, double* sm, const char* __restrict__ img, int lane, Prof& pr,
+                                        bool root_is_unit = false) {
   PROF_BEGIN(pr);
   const int nb = D.nb;
   double* q = sm + LD.q;
@@ -59,8 +60,11 @@ __device__ __forceinline__ void fk_wide(const WideDims& D, double* sm, const cha
     const uint2 ci = img_at<uint2>(img, IM.fki)[lane];
     hops = ci.x; dep = ci.y & 255u; hinge = (int)(ci.y >> 8) - 1;
     if (lane == 0) {
-      quat = qnormalize(d4{q[3], q[4], q[5], q[6]});
-      q[3] = quat.w; q[4] = quat.x; q[5] = quat.y; q[6] = quat.z;
+      quat = d4{q[3], q[4], q[5], q[6]};
+      if (!root_is_unit) {          // (a q_out row read back by the next chunk went through here already: normalising
+        quat = qnormalize(quat);    //  twice is not idempotent in the last bit)
+        q[3] = quat.w; q[4] = quat.x; q[5] = quat.y; q[6] = quat.z;
+      }
       pos = d3{q[0], q[1], q[2]};
     } else {
       const double* c = img_at<double>(img, IM.fkc) + 10 * lane;
@@ -671,16 +675,58 @@ __device__ __forceinline__ void preprocess_wide(const WideDims& D, double* sm, c
 
 // ---------------------------------------------------------------------------------------------
 // the kernel
+//
+// Two dispatch modes of the same body:
+//   direct  (Q.ring == nullptr)  workgroup s owns stream s for all of its frames;
+//   queued                       a resident set of wavefronts serves (stream, chunk of Q.chunk frames) items from a FIFO
+//                                in device memory.  A stream's next chunk is appended when its previous one is done (its
+//                                state -- q is the last q_out row, the QP's bound sets, the status -- lives in global
+//                                memory in between), so all streams advance together and the launch ends within about
+//                                one chunk of its last stream instead of within one whole stream: with a few thousand
+//                                resident wavefronts and streams of very different cost that tail was a fifth of the
+//                                launch.  Results are bit-identical to the direct mode.
+// Queue protocol: ticket i = atomicAdd(head); tickets >= nchunk (the total number of chunks, counted by the init kernel)
+// end the wavefront; ring[i] != 0 publishes stream ring[i] - 1 (release store after the chunk's rows and state; the
+// consumer's acquire fence follows its poll).  Entries [0, S) are the first chunks, written by the init kernel; push j
+// lands in ring[S + j]; the ring has nchunk entries, so no slot is reused.  A ticket below nchunk always gets its
+// entry: the pushes still missing belong to chunks held by wavefronts that are running.
 // ---------------------------------------------------------------------------------------------
+struct WideStreamState { unsigned long long lower, upper; int t_next, stat; };
+
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+struct WideQueue {
+  unsigned* hdr;                 // [0] head (tickets), [1] tail (pushes, starts at S), [2] nchunk
+  unsigned* ring;
+  WideStreamState* state;
+  int chunk;
+};
+
+__global__ void wide_queue_init(WideQueue Q, const int32_t* __restrict__ len, int S, int T, unsigned nring) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned n = 0;
+  if (i < (unsigned)S) {
+    const int Ts = len ? min(max(len[i], 0), T) : T;
+    n = Ts > 0 ? (unsigned)((Ts + Q.chunk - 1) / Q.chunk) : 1u;       // an empty stream is one (empty) chunk
+    Q.state[i] = WideStreamState{0ull, 0ull, 0, GMR_STATUS_OK};
+  }
+  if (i < nring) Q.ring[i] = i < (unsigned)S ? i + 1u : 0u;
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(&Q.hdr[2], n);
+  if (i == 0) Q.hdr[1] = (unsigned)S;
+}
+
 __global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(
     const char* __restrict__ img, WideDims D, int max_iter, int human_root, int use0, int use1, int S, int T,
     const double* __restrict__ q0, const double* __restrict__ human, const int32_t* __restrict__ len, int flags,
-    double* __restrict__ q_out, int32_t* __restrict__ nsolve, int32_t* __restrict__ status, double* __restrict__ tgt_out,
-    double* __restrict__ err_out, unsigned long long* __restrict__ prof_out) {
+    double* q_out, int32_t* __restrict__ nsolve, int32_t* __restrict__ status, double* __restrict__ tgt_out,
+    double* __restrict__ err_out, WideQueue Q, unsigned long long* __restrict__ prof_out) {
   extern __shared__ __align__(16) double sm[];
   const int lane = threadIdx.x;
-  const int s = blockIdx.x;
-  if (s >= S) return;
+  const bool queued = Q.ring != nullptr;
+  if (!queued && (int)blockIdx.x >= S) return;
   Prof pr;
 #ifdef GMR_IK_PROFILE
   for (int i = 0; i < PH_COUNT; i++) pr.acc[i] = 0;
@@ -688,28 +734,54 @@ __global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(
 #endif
   const int nq = D.nq, nhum = D.nhum;
   const double* prm = img_at<double>(img, IM.prm);   // damping, lm_damping, tol, limit_gain, ground_offset, dt
+  const unsigned nchunk = queued ? Q.hdr[2] : 0u;
+  const size_t fstride = (size_t)nhum * 7;
+  for (;;) {
+  int s = blockIdx.x, t0 = 0, stat = GMR_STATUS_OK;
+  RowState bounds = {0ull, 0ull};
+  if (queued) {
+    unsigned ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(&Q.hdr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket >= nchunk) break;
+    unsigned v = 0;
+    for (;;) {
+      if (lane == 0) v = __hip_atomic_load(&Q.ring[ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = __builtin_amdgcn_readfirstlane(v);
+      if (v) break;
+      __builtin_amdgcn_s_sleep(64);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the producer's q_out row and state are visible from here
+    s = (int)v - 1;
+    const WideStreamState st = Q.state[s];
+    bounds.lower = uniform64(st.lower); bounds.upper = uniform64(st.upper);
+    t0 = __builtin_amdgcn_readfirstlane(st.t_next);
+    stat = __builtin_amdgcn_readfirstlane(st.stat);
+  }
   // state that must start defined: the violation sets of the QP (double-buffered, cleared round by round)
   if (lane < 8) reinterpret_cast<unsigned long long*>(sm + LD.vset)[lane] = 0ull;
-  for (int i = lane; i < nq; i += 64) (sm + LD.q)[i] = q0[(size_t)s * nq + i];
+  {
+    const double* qs = t0 == 0 ? q0 + (size_t)s * nq : q_out + ((size_t)s * T + t0 - 1) * nq;
+    for (int i = lane; i < nq; i += 64) (sm + LD.q)[i] = qs[i];
+  }
   wsync();
   hinge_sincos(D, sm, lane);
   wsync();
-  fk_wide(D, sm, img, lane, pr);
+  fk_wide(D, sm, img, lane, pr, t0 > 0);
 
   const int Ts = len ? min(len[s], T) : T;
-  const size_t fstride = (size_t)nhum * 7;
+  const int t1 = queued ? min(t0 + Q.chunk, Ts) : Ts;
   const double* hs = human + (size_t)s * T * fstride;
-  int stat = GMR_STATUS_OK;
-  RowState bounds = {0ull, 0ull};
   double r0 = 0.0, r1 = 0.0;
-  if (Ts > 0) {
-    if (lane < (int)fstride) r0 = hs[lane];
-    if (lane + 64 < (int)fstride) r1 = hs[lane + 64];
+  if (t0 < t1) {
+    const double* nx = hs + (size_t)t0 * fstride;
+    if (lane < (int)fstride) r0 = nx[lane];
+    if (lane + 64 < (int)fstride) r1 = nx[lane + 64];
   }
-  for (int t = 0; t < Ts; t++) {
+  for (int t = t0; t < t1; t++) {
     if (lane < (int)fstride) (sm + LD.raw)[lane] = r0;
     if (lane + 64 < (int)fstride) (sm + LD.raw)[lane + 64] = r1;
-    if (t + 1 < Ts) {                                  // prefetch the next frame (nhuman * 7 <= 112 doubles)
+    if (t + 1 < t1) {                                  // prefetch the next frame (nhuman * 7 <= 112 doubles)
       const double* nx = hs + (size_t)(t + 1) * fstride;
       if (lane < (int)fstride) r0 = nx[lane];
       if (lane + 64 < (int)fstride) r1 = nx[lane + 64];
@@ -772,12 +844,29 @@ __global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(
     if (lane == 0) { nsolve[2 * f] = ns0; nsolve[2 * f + 1] = ns1; }
     wsync();
   }
-  if (lane == 0) status[s] = stat;
+  if (!queued) {
+    if (lane == 0) status[s] = stat;
+    break;
+  }
+  if (t1 < Ts) {
+    // hand the stream back: state, then (release) its ring entry.  The q_out rows of this chunk were stored by all
+    // lanes; the fence is executed by the wavefront, so it covers them.
+    if (lane == 0) Q.state[s] = WideStreamState{bounds.lower, bounds.upper, t1, stat};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) {
+      const unsigned slot = __hip_atomic_fetch_add(&Q.hdr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&Q.ring[slot], (unsigned)s + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else if (lane == 0) {
+    status[s] = stat;
+  }
+  wsync();
+  }
 #ifdef GMR_IK_PROFILE
   pr.acc[PH_TICKS] = __builtin_amdgcn_s_memtime() - k_t0;
   pr.acc[PH_REALTIME] = __builtin_amdgcn_s_memrealtime() - k_r0;
-  if (lane == 0 && prof_out)
-    for (int i = 0; i < PH_COUNT; i++) prof_out[(size_t)s * PH_COUNT + i] = pr.acc[i];
+  if (lane == 0 && prof_out && !queued)
+    for (int i = 0; i < PH_COUNT; i++) prof_out[(size_t)blockIdx.x * PH_COUNT + i] = pr.acc[i];
 #else
   (void)prof_out;
 #endif
@@ -786,15 +875,91 @@ __global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(
 }  // namespace wide
 }  // namespace gmr
 
-// host-side launcher used by gmr_abi.hip
+// ---------------------------------------------------------------------------------------------
+// host side: the launcher used by gmr_abi.hip and the queue workspaces of a solver
+// ---------------------------------------------------------------------------------------------
+#include <map>
+#include <mutex>
+
+namespace {
+
+struct QueueWs { char* base = nullptr; size_t bytes = 0; };
+struct WidePool {
+  std::mutex mu;
+  std::map<hipStream_t, QueueWs> ws;       // one workspace per HIP stream: launches on one stream are ordered
+  int slots = 0;                           // resident wavefronts of the device (the queued grid)
+  int chunk = 2;                           // frames per queue item
+  int min_streams_per_slot = 2;            // below this many streams per slot the direct mode is as good
+};
+
+}  // namespace
+
+extern "C" void* gmr_ik_wide_pool_create() {
+  WidePool* p = new WidePool();
+  int dev = 0, ncu = 0, nblk = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(gmr::wide::ik_wide_kernel), 64,
+                                                   gmr::WD_LDS_BYTES) != hipSuccess)
+    ncu = nblk = 0;
+  p->slots = ncu * nblk;
+  if (const char* e = getenv("GMR_IK_CHUNK")) p->chunk = atoi(e);      // 0 = always direct
+  if (const char* e = getenv("GMR_IK_QUEUE_MIN")) p->min_streams_per_slot = std::max(1, atoi(e));
+  return p;
+}
+
+extern "C" void gmr_ik_wide_pool_set_chunk(void* pool, int chunk) {
+  WidePool* p = static_cast<WidePool*>(pool);
+  std::lock_guard<std::mutex> g(p->mu);
+  p->chunk = chunk;
+}
+
+extern "C" void gmr_ik_wide_pool_destroy(void* pool) {
+  WidePool* p = static_cast<WidePool*>(pool);
+  if (!p) return;
+  for (auto& kv : p->ws) if (kv.second.base) (void)hipFree(kv.second.base);
+  delete p;
+}
+
 extern "C" hipError_t gmr_launch_ik_wide(const char* d_image, const gmr::WideLayout* L, const gmr::IkParams* P, int S, int T,
                                          const double* d_q0, const double* d_human, const int32_t* d_len, int flags,
                                          double* d_q_out, int32_t* d_nsolve, int32_t* d_status, double* d_tgt_out,
-                                         double* d_err_out, hipStream_t stream, unsigned long long* d_prof) {
+                                         double* d_err_out, hipStream_t stream, unsigned long long* d_prof, void* pool) {
   if (S <= 0 || T <= 0) return hipSuccess;
-  hipLaunchKernelGGL(gmr::wide::ik_wide_kernel, dim3(S), dim3(64), gmr::WD_LDS_BYTES, stream, d_image,
+  WidePool* p = static_cast<WidePool*>(pool);
+  gmr::wide::WideQueue Q{nullptr, nullptr, nullptr, 0};
+  int grid = S, chunk = 0;
+  if (p) { std::lock_guard<std::mutex> g(p->mu); chunk = p->chunk; }
+  // queued mode pays only when streams outnumber the resident wavefronts and have more than one chunk
+  if (p && !d_prof && chunk > 0 && p->slots > 0 && T > chunk && (long long)S >= (long long)p->slots * p->min_streams_per_slot) {
+    const size_t nring = (size_t)S * (size_t)((T + chunk - 1) / chunk);
+    const size_t o_ring = 256, o_state = o_ring + (nring * 4 + 255) / 256 * 256;
+    const size_t total = o_state + (size_t)S * sizeof(gmr::wide::WideStreamState);
+    char* base = nullptr;
+    {
+      std::lock_guard<std::mutex> g(p->mu);
+      QueueWs& w = p->ws[stream];
+      if (w.bytes < total) {
+        hipError_t e = hipSuccess;
+        if (w.base) { if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e; (void)hipFree(w.base); w.base = nullptr; w.bytes = 0; }
+        if ((e = hipMalloc((void**)&w.base, total)) != hipSuccess) return e;
+        w.bytes = total;
+      }
+      base = w.base;
+    }
+    Q.hdr = reinterpret_cast<unsigned*>(base);
+    Q.ring = reinterpret_cast<unsigned*>(base + o_ring);
+    Q.state = reinterpret_cast<gmr::wide::WideStreamState*>(base + o_state);
+    Q.chunk = chunk;
+    hipError_t e = hipMemsetAsync(base, 0, 256, stream);
+    if (e != hipSuccess) return e;
+    const unsigned nthr = (unsigned)std::max(nring, (size_t)S);
+    hipLaunchKernelGGL(gmr::wide::wide_queue_init, dim3((nthr + 255) / 256), dim3(256), 0, stream, Q, d_len, S, T, (unsigned)nring);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    grid = std::min(S, p->slots);
+  }
+  hipLaunchKernelGGL(gmr::wide::ik_wide_kernel, dim3(grid), dim3(64), gmr::WD_LDS_BYTES, stream, d_image,
                      static_cast<const gmr::WideDims&>(*L), P->max_iter, P->human_root, P->use0, P->use1, S, T, d_q0, d_human,
-                     d_len, flags, d_q_out, d_nsolve, d_status, d_tgt_out, d_err_out, d_prof);
+                     d_len, flags, d_q_out, d_nsolve, d_status, d_tgt_out, d_err_out, Q, d_prof);
   return hipGetLastError();
 }
 

@@ -659,3 +659,38 @@ def test_many_joints_on_their_limits(hip, oracle, src, robot):
         assert (st_h == 0).all() and np.array_equal(ns_h, ns_o), waves
         joint, pos, rot = _compare(q_h, q_o)
         assert joint <= 1e-9 and pos <= 1e-9 and rot <= 1e-9, (waves, joint, pos, rot)
+
+
+@pytest.mark.gpu
+def test_queued_dispatch_is_bit_identical_to_direct(hip, oracle, g1):
+    """Streams outnumbering the resident wavefronts are served from a device-side FIFO of (stream, chunk) items;
+    whatever the chunk, the bits are those of one workgroup per stream: ragged lengths, empty streams, a failing
+    stream, offset_to_ground, the optional outputs."""
+    from general_motion_retargeting_amd import synth
+    nb, S, T = 96, 6000, 7
+    bh, bq = synth.make_streams(g1.model, g1.tt, nb, T, seed=11)
+    rng = np.random.default_rng(5)
+    pick = rng.integers(0, nb, size=S)
+    human, q0 = bh[pick].copy(), bq[pick].copy()
+    lens = rng.integers(0, T + 1, size=S).astype(np.int32)
+    lens[:8] = [7, 0, 1, 2, 3, 7, 7, 0]
+    human[5, 3, 0, 3:] = np.nan                   # stream 5 fails in frame 3
+    sol = hip.Solver(g1.mb, g1.ts)
+    sol.set_waves(1)
+    sol.set_dispatch(0)
+    ref = sol.retarget_streams(q0, human, lens=lens, flags=hip.FLAG_OFFSET_TO_GROUND, want_targets=True, want_errors=True)
+    assert ref[2][5] == hip.STATUS_QP_FAILED and (np.delete(ref[2], 5) == 0).all()
+    for chunk in (1, 2, 3, 6):
+        sol.set_dispatch(chunk)
+        out = sol.retarget_streams(q0, human, lens=lens, flags=hip.FLAG_OFFSET_TO_GROUND, want_targets=True, want_errors=True)
+        for a, b in zip(ref, out):
+            assert np.array_equal(a, b, equal_nan=True), chunk
+    # and the oracle agrees on a few of them
+    for s in (0, 3, 4, 100, 5999):
+        n = int(lens[s])
+        if n == 0:
+            continue
+        q_o, ns_o, _ = oracle.retarget_streams(g1.mb, g1.ts, q0[s:s + 1], human[s:s + 1, :n], offset_to_ground=True)
+        assert np.array_equal(ref[1][s, :n], ns_o[0]) and np.abs(ref[0][s, :n] - q_o[0]).max() <= TOL_RAD
+    with pytest.raises(hip.GmrHipError):
+        sol.set_dispatch(-1)
