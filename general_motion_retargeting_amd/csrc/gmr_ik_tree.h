@@ -142,20 +142,23 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
     for (int p = 0; p < TR_NL; p++) {
       const int lane = fresh_lane(lane0);                    // (lane > p), (lane == p): computed here, dead after this pivot
       bad = bad || !(dp > 0.0);
-      double l = lane > p ? r[p] * dinv : 0.0;               // column p of L_l (rows > p) and of Y_l
-      if (lane == p) { mydinv = dinv; r[p] = dp * dinv; } else r[p] = l;
+      const double rs = r[p] * dinv;                         // (row p holds the pivot itself: d_p / sqrt(d_p))
+      double l = lane > p ? rs : 0.0;                        // column p of L_l (rows > p) and of Y_l
+      r[p] = lane == p ? rs : l;
+      if (lane == p) mydinv = dinv;
       double dinv_next = 1.0;
       if (p + 1 < TR_NL) {
         r[p + 1] = fma(-l, TR_BCAST(l, p + 1), r[p + 1]);
         dp = TR_BCAST(r[p + 1], p + 1);
         dinv_next = fast_rsqrt(dp);
       }
-      const double yp = TR_BCAST(b, p) * dinv;
-      b = lane == p ? yp : fma(-l, yp, b);
+      const double yp = TR_BCAST(b, p) * dinv;               // row p keeps its unscaled b (l = 0 there): scaled after the loop
+      b = fma(-l, yp, b);
 #pragma unroll
       for (int k = (p + 1 < TR_NL ? p + 2 : p + 1); k < TR_NV; k++) r[k] = fma(-l, TR_BCAST(l, k), r[k]);
       dinv = dinv_next;
     }
+    if (fresh_lane(lane0) < TR_NL) b *= mydinv;              // y_p = b_p / sqrt(d_p): the value every later row was given
     PROF_END(pr, PH_CHOL);
     PROF_BEGIN(pr);
     // ---- (3) publish the Schur contribution; park L_l / Y_l for the transposed reads --------------
@@ -216,8 +219,10 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
       for (int q = 0; q < TR_NT; q++) {
         const int t = fresh_lane(lane0) - TR_NL;             // (t > q), (t == q): computed here, dead after this pivot
         tbad = tbad || !(dq > 0.0);
-        double l = t > q ? s[q] * dinv : 0.0;
-        if (t == q) { tdinv = dinv; s[q] = dq * dinv; } else s[q] = l;
+        const double ss = s[q] * dinv;
+        double l = t > q ? ss : 0.0;
+        s[q] = t == q ? ss : l;
+        if (t == q) tdinv = dinv;
         double dinv_next = 1.0;
         if (q + 1 < TR_NT) {
           s[q + 1] = fma(-l, TR_BCAST(l, TR_NL + q + 1), s[q + 1]);
@@ -225,7 +230,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
           dinv_next = fast_rsqrt(dq);
         }
         const double yq = TR_BCAST(bt, TR_NL + q) * dinv;
-        bt = t == q ? yq : fma(-l, yq, bt);
+        bt = fma(-l, yq, bt);
 #pragma unroll
         for (int k = q + 2; k < TR_NT; k++) s[k] = fma(-l, TR_BCAST(l, TR_NL + k), s[k]);
         dinv = dinv_next;
@@ -241,14 +246,17 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #pragma unroll
-        for (int q = 0; q < TR_NT; q++) lt[q] = is_trunk ? Tscr[(TR_NL + q) * TR_LD + t] : 0.0;
+        // row t of L^T without its diagonal (the rows below are zero, rows outside the trunk get zeros): row q is final
+        // when its step comes, so no step needs a select
+        for (int q = 0; q < TR_NT; q++) lt[q] = (is_trunk && t != q) ? Tscr[(TR_NL + q) * TR_LD + t] : 0.0;
       }
+      bt *= tdinv;                                           // y (rows kept their unscaled right-hand side)
 #pragma unroll
       for (int q = TR_NT - 1; q >= 0; q--) {
-        const int t = fresh_lane(lane0) - TR_NL;             // rows outside the trunk have t < 0 or t >= TR_NT: lt = 0 there
         const double xq = TR_BCAST(bt * tdinv, TR_NL + q);
-        bt = t == q ? xq : (t >= 0 && t < q ? fma(-lt[q], xq, bt) : bt);
+        bt = fma(-lt[q], xq, bt);
       }
+      bt *= tdinv;                                           // x
     }
     PROF_END(pr, PH_RATIO);
     PROF_BEGIN(pr);
@@ -260,7 +268,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
       {
         TR_ROW()
 #pragma unroll
-        for (int m = 0; m < TR_NL; m++) lt[m] = is_limb ? Lscr[m * TR_LD + a] : 0.0;   // column a of L_l
+        for (int m = 0; m < TR_NL; m++) lt[m] = (is_limb && m != a) ? Lscr[m * TR_LD + a] : 0.0;   // column a of L_l, off-diagonal
 #pragma unroll
         for (int u = 0; u < TR_NT; u++) {
           const double xt = TR_BCAST(bt, TR_NL + u);
@@ -269,11 +277,10 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
       }
 #pragma unroll
       for (int p = TR_NL - 1; p >= 0; p--) {
-        const int lane = fresh_lane(lane0);
         const double xp = TR_BCAST(bb * mydinv, p);
-        bb = lane == p ? xp : (lane < p ? fma(-lt[p], xp, bb) : bb);
+        bb = fma(-lt[p], xp, bb);                            // (rows >= p have lt[p] = 0: row p is final at its step)
       }
-      if (fresh_lane(lane0) < TR_NL) x = bb;
+      if (fresh_lane(lane0) < TR_NL) x = bb * mydinv;
     }
     // ---- (6) violated bounds (free set) / multipliers (fixed set): g = H x + c ---------------------
     if (fixedm != 0ull) {                                     // multipliers need the whole x

@@ -386,16 +386,18 @@ __device__ __forceinline__ int solve_rows(const WideDims& D, double* sm, const c
 #pragma unroll
     for (int p = 0; p < NL; p++) {
       bad = bad || !(dp > 0.0);
-      double l = lane > p ? r[p] * dinv : 0.0;               // column p of L_g (rows > p) and of Y_g
-      if (lane == p) { mydinv = dinv; r[p] = dp * dinv; } else r[p] = l;
+      const double rs = r[p] * dinv;                         // (row p holds the pivot itself: d_p / sqrt(d_p))
+      double l = lane > p ? rs : 0.0;                        // column p of L_g (rows > p) and of Y_g
+      r[p] = lane == p ? rs : l;
+      if (lane == p) mydinv = dinv;
       double dinv_next = 1.0;
       if (p + 1 < NL) {
         r[p + 1] = fma(-l, row_bcast_d(l, p + 1), r[p + 1]);
         dp = row_bcast_d(r[p + 1], p + 1);
         dinv_next = fast_rsqrt(dp);
       }
-      const double yp = row_bcast_d(b, p) * dinv;
-      b = lane == p ? yp : fma(-l, yp, b);
+      const double yp = row_bcast_d(b, p) * dinv;            // row p keeps its unscaled b (l = 0 there): scaled after the loop
+      b = fma(-l, yp, b);
 #ifdef GMR_WIDE_MFMA_SCHUR
 #pragma unroll
       for (int k = (p + 1 < NL ? p + 2 : p + 1); k < NL; k++) r[k] = fma(-l, row_bcast_d(l, k), r[k]);   // limb columns only
@@ -405,6 +407,7 @@ __device__ __forceinline__ int solve_rows(const WideDims& D, double* sm, const c
 #endif
       dinv = dinv_next;
     }
+    if (is_limb) b *= mydinv;                                // y_p = b_p / sqrt(d_p): the value every later row was given
     PROF_END(pr, PH_CHOL);
     PROF_BEGIN(pr);
     // ---- (3) publish the Schur contribution; park L_g / Y_g for the transposed reads --------------
@@ -487,8 +490,10 @@ __device__ __forceinline__ int solve_rows(const WideDims& D, double* sm, const c
 #pragma unroll
       for (int q = 0; q < NT; q++) {
         tbad = tbad || !(dq > 0.0);
-        double l = t > q ? s[q] * dinv2 : 0.0;
-        if (t == q) { tdinv = dinv2; s[q] = dq * dinv2; } else s[q] = l;
+        const double ss = s[q] * dinv2;
+        double l = t > q ? ss : 0.0;
+        s[q] = t == q ? ss : l;
+        if (t == q) tdinv = dinv2;
         double dinv_next = 1.0;
         if (q + 1 < NT) {
           s[q + 1] = fma(-l, row_bcast_d(l, NL + q + 1), s[q + 1]);
@@ -496,7 +501,7 @@ __device__ __forceinline__ int solve_rows(const WideDims& D, double* sm, const c
           dinv_next = fast_rsqrt(dq);
         }
         const double yq = row_bcast_d(bt, NL + q) * dinv2;
-        bt = t == q ? yq : fma(-l, yq, bt);
+        bt = fma(-l, yq, bt);
 #pragma unroll
         for (int k = q + 2; k < NT; k++) s[k] = fma(-l, row_bcast_d(l, NL + k), s[k]);
         dinv2 = dinv_next;
@@ -507,14 +512,18 @@ __device__ __forceinline__ int solve_rows(const WideDims& D, double* sm, const c
         for (int u = 0; u < NT; u++) Tsh[t * WD_TT + u] = s[u];
       }
       wsync();
+      // row t of L^T without its diagonal (rows below are zero, other lanes get zeros): x_q = bt_q / L_qq twice scaled --
+      // once for y (forward), once here -- and row q is final when its step comes, so no step needs a select
       double lt[NT];
 #pragma unroll
-      for (int q = 0; q < NT; q++) lt[q] = is_trunk ? Tsh[q * WD_TT + t] : 0.0;
+      for (int q = 0; q < NT; q++) lt[q] = (is_trunk && t != q) ? Tsh[q * WD_TT + t] : 0.0;
+      bt *= tdinv;                                           // y
 #pragma unroll
       for (int q = NT - 1; q >= 0; q--) {
         const double xq = row_bcast_d(bt * tdinv, NL + q);
-        bt = t == q ? xq : (is_trunk && t < q ? fma(-lt[q], xq, bt) : bt);
+        bt = fma(-lt[q], xq, bt);
       }
+      bt *= tdinv;                                           // x
     }
     PROF_END(pr, PH_RATIO);
     PROF_BEGIN(pr);
@@ -523,7 +532,7 @@ __device__ __forceinline__ int solve_rows(const WideDims& D, double* sm, const c
     {
       double lt[NL];
 #pragma unroll
-      for (int m = 0; m < NL; m++) lt[m] = is_limb ? Lscr[m * TLD + a] : 0.0;          // column a of L_g
+      for (int m = 0; m < NL; m++) lt[m] = (is_limb && m != a) ? Lscr[m * TLD + a] : 0.0;   // column a of L_g, off-diagonal
       double bb = b;                                                                   // y_g (limb lanes)
 #pragma unroll
       for (int u = 0; u < NT; u++) {
@@ -533,9 +542,9 @@ __device__ __forceinline__ int solve_rows(const WideDims& D, double* sm, const c
 #pragma unroll
       for (int p = NL - 1; p >= 0; p--) {
         const double xp = row_bcast_d(bb * mydinv, p);
-        bb = lane == p ? xp : (lane < p ? fma(-lt[p], xp, bb) : bb);
+        bb = fma(-lt[p], xp, bb);                            // (rows >= p have lt[p] = 0: row p is final at its step)
       }
-      if (is_limb) x = bb;
+      if (is_limb) x = bb * mydinv;
     }
     // ---- (6) violated bounds (free set) / multipliers (fixed set): g = H x + c ---------------------
     if (fixedm != 0ull) {                                     // multipliers need the whole x, by owner lane
