@@ -182,7 +182,7 @@ __device__ __forceinline__ double errors_wave(const LT& L, double* sm, const sho
 // ---------------------------------------------------------------------------------------------
 struct StageTabs {
   const short* task_body; const short* task_human; const short* pair_task; const short* pair_dof;
-  const short* pair_index; const uint32_t* items;
+  const short* pair_index; const uint2* items;      // 64-bit schedule items (gmr_ik_layout.h)
 };
 
 // (a) lane = task: M_k = -Jl^-1(e_k) (blocks -A, -B), weighted residual; returns the LM term mu
@@ -272,6 +272,7 @@ __device__ __forceinline__ void pairs_phase(const LT& L, double* sm, int stage, 
     }
     cpart[p] = cp;   // this column's contribution to c = sum_k (W J_k)^T (W e_k)
   }
+  if (vlane < 6) Jw[6 * L.o.cap.p + vlane] = 0.0;   // the row that schedule items without a term read
 }
 
 // (b1) 4-wavefront shape, helpers only, right after the FK and concurrently with the main wavefront's residual
@@ -336,6 +337,7 @@ __device__ __forceinline__ void pairs_from_jbody(const LT& L, double* sm, int st
     }
     cpart[p] = cp;
   }
+  if (vlane < 6) Jw[6 * L.o.cap.p + vlane] = 0.0;   // the row that schedule items without a term read
 }
 
 // (c) lane = dof: gather c; bounds of the limited hinges (mink ConfigurationLimit)
@@ -367,68 +369,58 @@ __device__ __forceinline__ void cvec_phase(const LT& L, double* sm, int stage, c
 // (d) H: every (virtual) lane sums the terms of the entries it owns (static schedule) and stores each
 // once.  The schedule is padded to a wave-uniform number of slots and stored [slot][lane]; two terms per
 // trip, operands of both loaded (as 16-B pieces) before any store (Jw read-only, H write-only).
-struct dd2 { double x, y; };
+struct __attribute__((aligned(16))) dd2 { double x, y; };   // Jw rows start on 16-byte boundaries: one b128 read per piece
 __device__ __forceinline__ double dot6v(const double* a, const double* b) {
   const dd2* pa = reinterpret_cast<const dd2*>(a);
   const dd2* pb = reinterpret_cast<const dd2*>(b);
   dd2 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
   return (a0.x * b0.x + a0.y * b0.y + a1.x * b1.x) + (a1.y * b1.y + a2.x * b2.x + a2.y * b2.y);
 }
+__device__ __forceinline__ double item_dot(const char* Jb, uint32_t lo) {
+  return dot6v(reinterpret_cast<const double*>(Jb + (lo & 0xffffu)), reinterpret_cast<const double*>(Jb + (lo >> 16)));
+}
+__device__ __forceinline__ void item_store(char* Hb, uint32_t hi, double acc, double diag) {
+  const double v = acc + ((hi & (1u << 30)) ? diag : 0.0);
+  *reinterpret_cast<double*>(Hb + (hi & 0x7fffu)) = v;
+  *reinterpret_cast<double*>(Hb + ((hi >> 15) & 0x7fffu)) = v;
+}
 
 template <class LT>
 __device__ __forceinline__ void hacc_phase(const LT& L, double* sm, int stage, const StageTabs& tb, double diag,
                                            int vlane) {
-  const int ldh = L.o.ldh, nl = L.nlanes, ntrip = L.ntrip[stage];
+  const int nl = L.nlanes, ntrip = L.ntrip[stage];
   const bool paired = vlane < L.pair_lanes;       // the whole first helper wavefront, or nobody
-  double* __restrict__ H = sm + L.o.H;
-  const double* __restrict__ J = sm + L.o.Jw;
-  const uint32_t* items = tb.items + vlane;
+  char* __restrict__ Hb = reinterpret_cast<char*>(sm + L.o.H);
+  const char* __restrict__ Jb = reinterpret_cast<const char*>(sm + L.o.Jw);
+  const uint2* items = tb.items + vlane;
   double acc = 0.0;
-  uint32_t n0 = items[0], n1 = items[nl];
-  for (int it = 0; it < ntrip; it += 2) {
-    const uint32_t w0 = n0, w1 = n1;
-    if (it + 2 < ntrip) { n0 = items[(it + 2) * nl]; n1 = items[(it + 3) * nl]; }   // next trip in flight
-    double s0 = dot6v(J + 6 * (w0 & 511u), J + 6 * ((w0 >> 9) & 511u));
-    double s1 = dot6v(J + 6 * (w1 & 511u), J + 6 * ((w1 >> 9) & 511u));
-    if ((w0 >> 30) & 1u) s0 = 0.0;
-    if ((w1 >> 30) & 1u) s1 = 0.0;
-    acc += s0;
-    if (paired) {   // wave-uniform: lanes 2i / 2i+1 hold the two halves of one entry, closed in the same slot
-      if (__any((int)(w0 >> 31))) {
-        double tot = acc + dpp_swap_pairs(acc);             // own + neighbour (commutative: the same bits in both lanes)
-        if ((w0 >> 31) && !(vlane & 1)) {
-          int da = (w0 >> 18) & 63u, db = (w0 >> 24) & 63u;
-          double v = tot + (da == db ? diag : 0.0);
-          H[da * ldh + db] = v;
-          H[db * ldh + da] = v;
-        }
-        if (w0 >> 31) acc = 0.0;
-      }
-    } else if (w0 >> 31) {
-      int da = (w0 >> 18) & 63u, db = (w0 >> 24) & 63u;
-      double v = acc + (da == db ? diag : 0.0);
-      H[da * ldh + db] = v;
-      H[db * ldh + da] = v;
-      acc = 0.0;
+  uint2 n[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) n[k] = items[k * nl];
+  for (int it = 0; it < ntrip; it += 4) {                  // four slots per trip: their row reads are in flight together
+    uint2 w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = n[k];
+    if (it + 4 < ntrip) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) n[k] = items[(it + 4 + k) * nl];
     }
-    acc += s1;
-    if (paired) {
-      if (__any((int)(w1 >> 31))) {
-        double tot = acc + dpp_swap_pairs(acc);
-        if ((w1 >> 31) && !(vlane & 1)) {
-          int da = (w1 >> 18) & 63u, db = (w1 >> 24) & 63u;
-          double v = tot + (da == db ? diag : 0.0);
-          H[da * ldh + db] = v;
-          H[db * ldh + da] = v;
+    double s[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) s[k] = item_dot(Jb, w[k].x);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      acc += s[k];
+      if (paired) {   // wave-uniform: lanes 2i / 2i+1 hold the two halves of one entry, closed in the same slot
+        if (__any((int)(w[k].y >> 31))) {
+          double tot = acc + dpp_swap_pairs(acc);           // own + neighbour (commutative: the same bits in both lanes)
+          if ((w[k].y >> 31) && !(vlane & 1)) item_store(Hb, w[k].y, tot, diag);
+          if (w[k].y >> 31) acc = 0.0;
         }
-        if (w1 >> 31) acc = 0.0;
+      } else if (w[k].y >> 31) {
+        item_store(Hb, w[k].y, acc, diag);
+        acc = 0.0;
       }
-    } else if (w1 >> 31) {
-      int da = (w1 >> 18) & 63u, db = (w1 >> 24) & 63u;
-      double v = acc + (da == db ? diag : 0.0);
-      H[da * ldh + db] = v;
-      H[db * ldh + da] = v;
-      acc = 0.0;
     }
   }
 }
@@ -437,17 +429,17 @@ __device__ __forceinline__ void hacc_phase(const LT& L, double* sm, int stage, c
 // stream on the CU: vector-L1 hits) instead of LDS, four slots per trip with the next trip in flight.
 template <class LT>
 __device__ __forceinline__ void hacc_phase_g(const LT& L, double* sm, int stage,
-                                             const uint32_t* __restrict__ gitems, double diag, int lane) {
-  const int ldh = L.o.ldh, ntrip = L.ntrip[stage];          // a multiple of 4, 64 lanes
-  double* __restrict__ H = sm + L.o.H;
-  const double* __restrict__ J = sm + L.o.Jw;
-  const uint32_t* p = gitems + lane;
-  uint32_t n[4];
+                                             const uint2* __restrict__ gitems, double diag, int lane) {
+  const int ntrip = L.ntrip[stage];                         // a multiple of 4, 64 lanes
+  char* __restrict__ Hb = reinterpret_cast<char*>(sm + L.o.H);
+  const char* __restrict__ Jb = reinterpret_cast<const char*>(sm + L.o.Jw);
+  const uint2* p = gitems + lane;
+  uint2 n[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) n[k] = p[k * 64];
   double acc = 0.0;
   for (int it = 0; it < ntrip; it += 4) {
-    uint32_t w[4];
+    uint2 w[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) w[k] = n[k];
     if (it + 4 < ntrip) {
@@ -456,18 +448,12 @@ __device__ __forceinline__ void hacc_phase_g(const LT& L, double* sm, int stage,
     }
     double s[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      s[k] = dot6v(J + 6 * (w[k] & 511u), J + 6 * ((w[k] >> 9) & 511u));
-      if ((w[k] >> 30) & 1u) s[k] = 0.0;
-    }
+    for (int k = 0; k < 4; k++) s[k] = item_dot(Jb, w[k].x);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       acc += s[k];
-      if (w[k] >> 31) {
-        int da = (w[k] >> 18) & 63u, db = (w[k] >> 24) & 63u;
-        double v = acc + (da == db ? diag : 0.0);
-        H[da * ldh + db] = v;
-        H[db * ldh + da] = v;
+      if (w[k].y >> 31) {
+        item_store(Hb, w[k].y, acc, diag);
         acc = 0.0;
       }
     }
@@ -527,7 +513,8 @@ __device__ __forceinline__ void helper_loop(const LT& L, double* sm, const uint3
     if (cmd == CMD_EXIT) return;
     const int stage = ctl[2 * (epoch & 1) + 1];
     StageTabs tb = {si + L.o.i_task_body[stage], si + L.o.i_task_human[stage], si + L.o.i_pair_task[stage],
-                    si + L.o.i_pair_dof[stage], si + L.o.i_pair_index[stage], sw + L.w_items[stage]};
+                    si + L.o.i_pair_dof[stage], si + L.o.i_pair_index[stage],
+                    reinterpret_cast<const uint2*>(sw + L.w_items[stage])};
     if (cmd == CMD_JBODY) {               // the main wavefront is evaluating the residuals meanwhile
       PROF_BEGIN(hp);
       jbody_phase(L, sm, stage, tb, (wave - 1) * 64 + lane, 64 * (NW - 1));
@@ -893,7 +880,8 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
         if (!(stage == 0 ? use0 : use1) || (flags & GMR_FLAG_EVAL_ONLY)) continue;
         const StageTabs tb = {si + L.o.i_task_body[stage], si + L.o.i_task_human[stage], si + L.o.i_pair_task[stage],
                               si + L.o.i_pair_dof[stage], si + L.o.i_pair_index[stage],
-                              NW == 1 ? reinterpret_cast<const uint32_t*>(image) + L.g_items[stage] : sw + L.w_items[stage]};
+                              reinterpret_cast<const uint2*>(NW == 1 ? reinterpret_cast<const uint32_t*>(image) + L.g_items[stage]
+                                                                     : sw + L.w_items[stage])};
         const int K = L.K[stage];
         if (h_stage != stage) {
           // structural zeros of H are never written by the schedule: clear when the pattern changes

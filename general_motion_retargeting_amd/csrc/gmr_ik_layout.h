@@ -69,7 +69,7 @@ constexpr IkOffsets ik_offsets(int nvp, int nw) {
   L.M = o; o += ik_max(18 * cp.k, 7 * cp.nhum + 1);
   L.raw = L.M;                                     // the raw frame is consumed by the preprocess step, before any solve
   if (o & 1) o++;                                  // Jw rows (48 B) are read as three 16-B pieces
-  L.Jw = o; o += ik_max(6 * cp.p, 7 * cp.nb + 1);
+  L.Jw = o; o += ik_max(6 * (cp.p + 1), 7 * cp.nb + 1);   // row cap.p stays zero: what items without a term read
   L.cpart = o; o += cp.p;
   L.xb = L.Jw;                                     // FK runs between solves, when the assembly scratch is dead
   // The transpose scratch of the QP solvers (dense: nvp x (nvp+1); tree: 4 x 18 x 19) is only live inside a
@@ -160,25 +160,28 @@ inline int ik_size_class(const gmr_model_t& m, const gmr_taskset_t& ts) {
 // and j.  Every (i >= j) entry with its list of (pair_a, pair_b) terms is owned by exactly ONE lane
 // (longest-processing-time assignment), which sums the terms in a fixed order in a register and
 // stores the entry once: no read-modify-write, no atomics, deterministic.
-// item word: [8:0] pair a, [17:9] pair b, [23:18] dof i, [29:24] dof j, [30] entry has no term,
-//            [31] last term of the entry
+// item (64 bit), pre-scaled to LDS byte offsets so that a term costs two integer instructions beside its six FMAs:
+//   lo  [15:0] byte offset of Jw row a, [31:16] of row b (an item without a term names the zero row `cap.p` twice)
+//   hi  [14:0] byte offset of H[i][j], [29:15] of H[j][i], [30] diagonal entry (the damping term is added),
+//       [31] last term of the entry
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t IK_ITEM_NOP = 1u << 30;   // contributes nothing (and, without bit 31, closes nothing)
+constexpr uint64_t ik_item_nop(int zero_row) { return (uint64_t)(48u * (uint32_t)zero_row) * 0x10001ull; }
 
 struct IkSchedule {
   int nlanes;                      // virtual lanes that share the assembly: 64 (one wave) or 192 (3 helpers)
   int pair_lanes;                  // lanes [0, pair_lanes) cooperate pairwise on one entry each
-  std::vector<uint32_t> items[2];
+  std::vector<uint64_t> items[2];
   std::vector<int> istart[2];      // nlanes + 1 offsets
   // what the kernel reads: every lane padded to ntrip slots with no-op words, stored [slot][lane] so that
   // a wave reads consecutive words (conflict-free) and the loop trip count is wave-uniform
   int ntrip[2];
   int npaired[2];                  // entries split over a lane pair
-  std::vector<uint32_t> padded[2];
+  std::vector<uint64_t> padded[2];
 };
 
-inline IkSchedule make_ik_schedule(const gmr_model_t& m, const gmr_taskset_t& ts, int nlanes) {
+inline IkSchedule make_ik_schedule(const gmr_model_t& m, const gmr_taskset_t& ts, int nlanes, int ldh, int zero_row) {
   IkSchedule sch;
+  const uint64_t NOP = ik_item_nop(zero_row);
   sch.nlanes = nlanes;
   // With three helper wavefronts (192 lanes) the longest entries (all tasks meet in the base x base
   // block) bound the phase.  The first wavefront's 64 lanes therefore work in PAIRS: lanes 2i and 2i+1
@@ -193,10 +196,14 @@ inline IkSchedule make_ik_schedule(const gmr_model_t& m, const gmr_taskset_t& ts
       for (int a = 0; a < n; a++)
         for (int b = 0; b <= a; b++) {
           int da = ts.pair_dof[s][c0 + a], db = ts.pair_dof[s][c0 + b];
-          terms[(size_t)da * nv + db].push_back((uint32_t)(c0 + a) | ((uint32_t)(c0 + b) << 9));
+          terms[(size_t)da * nv + db].push_back(48u * (uint32_t)(c0 + a) | ((48u * (uint32_t)(c0 + b)) << 16));
         }
     }
     struct Ent { int da, db, w; };
+    auto dest = [&](const Ent& e) {
+      return (uint64_t)((uint32_t)(8 * (e.da * ldh + e.db)) | ((uint32_t)(8 * (e.db * ldh + e.da)) << 15) |
+                        (e.da == e.db ? 1u << 30 : 0u)) << 32;
+    };
     std::vector<Ent> ents;
     for (int da = 0; da < nv; da++)
       for (int db = 0; db <= da; db++) {
@@ -235,30 +242,29 @@ inline IkSchedule make_ik_schedule(const gmr_model_t& m, const gmr_taskset_t& ts
         const auto& tt = terms[(size_t)e.da * nv + e.db];
         const size_t half = (tt.size() + 1) / 2;              // both lanes get `half` slots
         const size_t lo2 = (l & 1) ? half : 0, hi2 = (l & 1) ? tt.size() : half;
-        uint32_t dd = ((uint32_t)e.da << 18) | ((uint32_t)e.db << 24);
+        const uint64_t dd = dest(e);
         for (size_t i = 0; i < half; i++) {
           const bool have = lo2 + i < hi2;
-          uint32_t w = (have ? tt[lo2 + i] : IK_ITEM_NOP) | dd;
-          if (i + 1 == half) w |= 1u << 31;                   // both lanes close the entry in the same slot
+          uint64_t w = (have ? (uint64_t)tt[lo2 + i] : NOP) | dd;
+          if (i + 1 == half) w |= 1ull << 63;                 // both lanes close the entry in the same slot
           sch.items[s].push_back(w);
         }
         continue;
       }
       for (const Ent& e : per_lane[l]) {
         const auto& tt = terms[(size_t)e.da * nv + e.db];
-        uint32_t dd = ((uint32_t)e.da << 18) | ((uint32_t)e.db << 24);
-        if (tt.empty()) sch.items[s].push_back(dd | (1u << 30) | (1u << 31));
+        const uint64_t dd = dest(e);
+        if (tt.empty()) sch.items[s].push_back(NOP | dd | (1ull << 63));
         for (size_t i = 0; i < tt.size(); i++)
-          sch.items[s].push_back(tt[i] | dd | (i + 1 == tt.size() ? (1u << 31) : 0u));
+          sch.items[s].push_back((uint64_t)tt[i] | dd | (i + 1 == tt.size() ? (1ull << 63) : 0ull));
       }
     }
     sch.istart[s][nlanes] = (int)sch.items[s].size();
     int nt = 0;
     for (int l = 0; l < nlanes; l++) nt = std::max(nt, sch.istart[s][l + 1] - sch.istart[s][l]);
-    nt = nlanes == 64 ? (nt + 3) & ~3         // four slots per loop trip (items streamed from global memory)
-                      : (nt + 1) & ~1;        // two slots per loop trip
+    nt = (nt + 3) & ~3;                       // four slots per loop trip
     sch.ntrip[s] = nt;
-    sch.padded[s].assign((size_t)nt * nlanes, IK_ITEM_NOP);
+    sch.padded[s].assign((size_t)nt * nlanes, NOP);
     for (int l = 0; l < nlanes; l++)
       for (int i = sch.istart[s][l]; i < sch.istart[s][l + 1]; i++)
         sch.padded[s][(size_t)(i - sch.istart[s][l]) * nlanes + l] = sch.items[s][i];
@@ -329,6 +335,12 @@ inline IkTree make_ik_tree(const gmr_model_t& m) {
   return tr;
 }
 
+// the schedule of a robot's size class (its H row stride and zero row)
+inline IkSchedule make_ik_schedule(const gmr_model_t& m, const gmr_taskset_t& ts, int nlanes) {
+  const int c = ik_size_class(m, ts), nvp = c > 0 ? c : 48;
+  return make_ik_schedule(m, ts, nlanes, nvp + 1, ik_caps(nvp).p);
+}
+
 inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, const IkSchedule& sch, int nw) {
   IkLayout L{};
   L.nw = nw;
@@ -355,13 +367,13 @@ inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, co
   int w = L.o.w_items0;
   for (int s = 0; s < 2; s++) {
     L.w_items[s] = nw == 1 ? 0 : w;
-    if (nw != 1) w += (L.nitem[s] + 3) / 4 * 4;
+    if (nw != 1) w += (2 * L.nitem[s] + 3) / 4 * 4;            // 64-bit items
     L.g_items[s] = -1;
   }
   L.smem_bytes = L.o.n_double * 8 + L.o.n_short * 2 + w * 4;
   L.image_bytes = L.smem_bytes;                    // a multiple of 16
   if (nw == 1)
-    for (int s = 0; s < 2; s++) { L.g_items[s] = L.image_bytes / 4; L.image_bytes += (L.nitem[s] * 4 + 15) / 16 * 16; }
+    for (int s = 0; s < 2; s++) { L.g_items[s] = L.image_bytes / 4; L.image_bytes += (L.nitem[s] * 8 + 15) / 16 * 16; }
   return L;
 }
 
@@ -425,7 +437,7 @@ inline std::vector<char> make_ik_image(const gmr_model_t& m, const gmr_taskset_t
   }
   for (int s = 0; s < 2; s++) {
     uint32_t* dst = L.g_items[s] >= 0 ? reinterpret_cast<uint32_t*>(img.data()) + L.g_items[s] : sw + L.w_items[s];
-    for (size_t i = 0; i < sch.padded[s].size(); i++) dst[i] = sch.padded[s][i];
+    std::memcpy(dst, sch.padded[s].data(), sch.padded[s].size() * 8);
     for (int k = 0; k < L.K[s]; k++) {
       si[L.o.i_task_body[s] + k] = (short)ts.task_body[s][k];
       si[L.o.i_task_human[s] + k] = (short)ts.task_human[s][k];

@@ -898,7 +898,7 @@ struct WidePool {
   std::map<hipStream_t, QueueWs> ws;       // one workspace per HIP stream: launches on one stream are ordered
   int slots = 0;                           // resident wavefronts of the device (the queued grid)
   int chunk = 2;                           // frames per queue item
-  int min_streams_per_slot = 2;            // below this many streams per slot the direct mode is as good
+  int min_streams_per_slot = 1;            // queued mode from slots * this + 1 streams (all resident: nothing to balance)
 };
 
 }  // namespace
@@ -939,7 +939,7 @@ extern "C" hipError_t gmr_launch_ik_wide(const char* d_image, const gmr::WideLay
   int grid = S, chunk = 0;
   if (p) { std::lock_guard<std::mutex> g(p->mu); chunk = p->chunk; }
   // queued mode pays only when streams outnumber the resident wavefronts and have more than one chunk
-  if (p && !d_prof && chunk > 0 && p->slots > 0 && T > chunk && (long long)S >= (long long)p->slots * p->min_streams_per_slot) {
+  if (p && !d_prof && chunk > 0 && p->slots > 0 && T > chunk && (long long)S > (long long)p->slots * p->min_streams_per_slot) {
     const size_t nring = (size_t)S * (size_t)((T + chunk - 1) / chunk);
     const size_t o_ring = 256, o_state = o_ring + (nring * 4 + 255) / 256 * 256;
     const size_t total = o_state + (size_t)S * sizeof(gmr::wide::WideStreamState);

@@ -28,6 +28,7 @@ int main(int argc, char** argv) {
   const int nv = m.nv;
   for (int nl : {64, 192}) {
     gmr::IkSchedule sch = gmr::make_ik_schedule(m, ts, nl);
+    const int cls = gmr::ik_size_class(m, ts), nvp = cls > 0 ? cls : 48, ldh = nvp + 1, zero_row = gmr::ik_caps(nvp).p;
     for (int s = 0; s < 2; s++) {
       // expected terms per entry
       std::map<std::pair<int, int>, std::multiset<std::pair<int, int>>> want;
@@ -49,9 +50,20 @@ int main(int argc, char** argv) {
         bool open = false;
         std::pair<int, int> cur;
         for (int i = sch.istart[s][l]; i < sch.istart[s][l + 1]; i++) {
-          uint32_t w = sch.items[s][i];
-          std::pair<int, int> e = {(int)((w >> 18) & 63u), (int)((w >> 24) & 63u)};
+          const uint64_t w64 = sch.items[s][i];
+          const uint32_t lo = (uint32_t)w64, hi = (uint32_t)(w64 >> 32);
+          // destinations are byte offsets of H[i][j] and H[j][i] (row stride ldh doubles); rows byte offsets of Jw rows
+          const int o1 = (int)(hi & 0x7fffu) / 8, o2 = (int)((hi >> 15) & 0x7fffu) / 8;
+          CHECK((hi & 7u) == 0 && ((hi >> 15) & 7u) == 0, "store offsets must be multiples of 8");
+          std::pair<int, int> e = {o1 / ldh, o1 % ldh};
+          CHECK(o2 == e.second * ldh + e.first, "the second store is the transposed entry");
           CHECK(e.first >= e.second && e.first < nv, "entry range");
+          CHECK(((hi >> 30) & 1u) == (e.first == e.second ? 1u : 0u), "diagonal flag");
+          CHECK((lo & 0xffffu) % 48 == 0 && (lo >> 16) % 48 == 0, "row offsets must be multiples of 48");
+          const int ra = (int)(lo & 0xffffu) / 48, rb = (int)(lo >> 16) / 48;
+          const bool nop = ra == zero_row;
+          CHECK(nop ? rb == zero_row : (ra < ts.npair[s] && rb < ts.npair[s]), "row range");
+          const uint32_t w = (nop ? 1u << 30 : 0u) | (hi & (1u << 31)) | (uint32_t)ra | ((uint32_t)rb << 9);
           const bool pairlane = l < 2 * sch.npaired[s];
           if (open) CHECK(e == cur, "terms of one entry must be contiguous in one lane");
           else { CHECK(pairlane ? (!(l & 1) ? !closed.count(e) : closed.count(e) == 1) : !closed.count(e),
