@@ -71,6 +71,42 @@ __device__ __forceinline__ void sincosf_small(float x, float* sn, float* cs) {
   *cs = ((q + 1) & 2) ? -cc : cc;
 }
 
+// One body of the walk: world rotation `rot` = prot * (r_j * joint(ang)) and the world offset of its origin
+// R(prot) t_j (reference kinematics_model.py:213-246).  Everything in `cur` is wave-uniform (SGPRs).
+// (Measured and not kept: skipping the products with the exact zeros / ones of a unit r_j or an axis +-e_k -- bit-equal,
+// 21 % fewer vector instructions, 25 % more scalar ones for the dispatch, no change in time: DESIGN.md section 4.2.)
+__device__ __forceinline__ void fk_body(const FkBodyRec& cur, float ang, f4 prot, float& wx, float& wy, float& wz, f4& rot) {
+  const f4 lr = {cur.r[0], cur.r[1], cur.r[2], cur.r[3]};
+  f4 cr = lr;
+  if (cur.meta & 1u) {
+    // dof_to_rot: sin/cos of the float32 half angle; products and the normalisation in float64;
+    // rounded to float32 on assignment (kinematics_model.py:21-36, torch_utils.py:353-359).
+    // the record's axis is normalize(axis) (float64, computed once on the host).
+    float th = ang / 2.0f;
+    float sf, cf;
+#ifdef GMR_FK_LIBM_SINCOS
+    sincosf(th, &sf, &cf);
+#else
+    sincosf_small(th, &sf, &cf);
+#endif
+    double s = (double)sf, c = (double)cf;
+    double qx = cur.axis[0] * s, qy = cur.axis[1] * s, qz = cur.axis[2] * s, qw = c;
+    // quat_unit in float64: x / |q|.  |q|^2 = 1 + e with |e| ~ 1e-7 (float32 sin / cos of one angle, a unit axis), so
+    // 1 / |q| = 1 - e/2 + 3 e^2 / 8 to 1e-21: the quotient differs from x / sqrt(|q|^2) by < 1 ulp of float64 and
+    // rounds to the same float32 (measured bit-equal with the rsqrt form on 2^20 random frames, tools/fk_bitcheck.py)
+#ifdef GMR_FK_RSQRT_NORM
+    double rn = rsqrt(fmax(qx * qx + qy * qy + qz * qz + qw * qw, 1e-18));
+#else
+    const double e = fma(qx, qx, fma(qy, qy, fma(qz, qz, fma(qw, qw, -1.0))));
+    const double rn = fma(e, fma(e, 0.375, -0.5), 1.0);
+#endif
+    f4 jr = {(float)(qx * rn), (float)(qy * rn), (float)(qz * rn), (float)(qw * rn)};
+    cr = qmul_xyzw(lr, jr);
+  }  // no joint: r_j * (0,0,0,1) == r_j exactly
+  qrot_xyzw(prot, cur.t[0], cur.t[1], cur.t[2], wx, wy, wz);
+  rot = qmul_xyzw(prot, cr);
+}
+
 constexpr int FK_BLOCK = 64;  // one wave per block
 
 template <bool STAGED>
@@ -143,34 +179,6 @@ __global__ __launch_bounds__(FK_BLOCK) void fk_batch_kernel(const FkTree* __rest
     const float ang = ang_nxt;
     if (STAGED) ang_nxt = (outb + tid * row)[3 * (j + 1 < nb ? j + 1 : j)];
     const int src = (int)((cur.meta >> 8) & 255u) - 1, dst = (int)((cur.meta >> 16) & 255u) - 1;
-    const float tx = cur.t[0], ty = cur.t[1], tz = cur.t[2];
-    f4 lr = {cur.r[0], cur.r[1], cur.r[2], cur.r[3]};
-    f4 cr = lr;
-    if (cur.meta & 1u) {
-      // dof_to_rot: sin/cos of the float32 half angle; products and the normalisation in float64;
-      // rounded to float32 on assignment (kinematics_model.py:21-36, torch_utils.py:353-359).
-      // the record's axis is normalize(axis) (float64, computed once on the host).
-      float th = (STAGED ? ang : drow[cur.dof_idx]) / 2.0f;
-      float sf, cf;
-#ifdef GMR_FK_LIBM_SINCOS
-      sincosf(th, &sf, &cf);
-#else
-      sincosf_small(th, &sf, &cf);
-#endif
-      double s = (double)sf, c = (double)cf;
-      double qx = cur.axis[0] * s, qy = cur.axis[1] * s, qz = cur.axis[2] * s, qw = c;
-      // quat_unit in float64: x / |q|.  |q|^2 = 1 + e with |e| ~ 1e-7 (float32 sin / cos of one angle, a unit axis), so
-      // 1 / |q| = 1 - e/2 + 3 e^2 / 8 to 1e-21: the quotient differs from x / sqrt(|q|^2) by < 1 ulp of float64 and
-      // rounds to the same float32 (measured bit-equal with the rsqrt form on 2^20 random frames, tools/fk_bitcheck.py)
-#ifdef GMR_FK_RSQRT_NORM
-      double rn = rsqrt(fmax(qx * qx + qy * qy + qz * qz + qw * qw, 1e-18));
-#else
-      const double e = fma(qx, qx, fma(qy, qy, fma(qz, qz, fma(qw, qw, -1.0))));
-      const double rn = fma(e, fma(e, 0.375, -0.5), 1.0);
-#endif
-      f4 jr = {(float)(qx * rn), (float)(qy * rn), (float)(qz * rn), (float)(qw * rn)};
-      cr = qmul_xyzw(lr, jr);
-    }  // no joint: r_j * (0,0,0,1) == r_j exactly
     float ppx = cpx, ppy = cpy, ppz = cpz;
     f4 prot = crot;
     if (src >= 0) {   // wave-uniform: this body is not the first child of the body before it
@@ -187,9 +195,9 @@ __global__ __launch_bounds__(FK_BLOCK) void fk_batch_kernel(const FkTree* __rest
       }
     }
     float wx, wy, wz;
-    qrot_xyzw(prot, tx, ty, tz, wx, wy, wz);
+    f4 rot;
+    fk_body(cur, STAGED ? ang : ((cur.meta & 1u) ? drow[cur.dof_idx] : 0.0f), prot, wx, wy, wz, rot);
     float px = ppx + wx, py = ppy + wy, pz = ppz + wz;
-    f4 rot = qmul_xyzw(prot, cr);
     cpx = px; cpy = py; cpz = pz; crot = rot;
     if (dst >= 0 && SW > 0) {
       float* cur = stk + dst * SW * FK_BLOCK;
@@ -252,6 +260,137 @@ __global__ __launch_bounds__(FK_BLOCK) void fk_batch_kernel(const FkTree* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The split walk: a block is still 64 frames (lane = frame) with its outputs staged in LDS, but up to four wavefronts
+// walk it, each its part of the tree (FkTree::wrec): the chain of ancestors its subtrees hang from -- recomputed by
+// every wavefront that needs it, a handful of bodies -- and then the subtrees themselves.  The staging area (456 B per
+// frame for the G1) limits a CU to five blocks whatever the kernel does; with one wavefront per block that is 1.25
+// wavefronts per SIMD walking 38 dependent bodies each (the wave issues 43 % of its cycles, profiles/r02_fk_*); with
+// four it is 5 per SIMD walking ~12.  Parents that are not the body walked just before come from per-wavefront slots
+// (position and rotation): no wavefront reads what another one wrote before the final barrier.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * FK_MAX_WAVES) void fk_split_kernel(const FkTree* __restrict__ tree, int B,
+                                                                     const float* __restrict__ root_pos,
+                                                                     const float* __restrict__ root_rot,
+                                                                     const float* __restrict__ dof,
+                                                                     float* __restrict__ body_pos,
+                                                                     float* __restrict__ body_rot,
+                                                                     float* __restrict__ min_part) {
+  extern __shared__ __align__(16) float fsm[];     // slots [nslot_split][7][64], pos [64][nb*3], rot [64][nb*4]
+  __shared__ float red[FK_MAX_WAVES];
+  const int nb = tree->nbody, ndof = tree->ndof, nwave = tree->nwave;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), tid = threadIdx.x & 63;
+  const long long f = (long long)blockIdx.x * 64 + tid;
+  const bool on = f < B;
+  const long long fc = on ? f : 0;
+  float* stk = fsm + tid;
+  const int row = nb * 3, rrow = nb * 4;
+  float* outb = fsm + tree->nslot_split * 7 * 64;
+  float* outr = outb + 64 * row;
+  float* orow = outb + tid * row;
+  float* rrow_p = outr + tid * rrow;
+  const float* drow = dof + fc * ndof;
+  const int i0 = tree->wave_start[wave], i1 = tree->wave_start[wave + 1];
+  float zmin = INFINITY;
+  // park the joint angles of the bodies this wavefront stores, each in the staging slot its position will overwrite:
+  // the loads of a lane's own dof row, all issued back to back (see fk_batch_kernel)
+#pragma unroll 8
+  for (int i = i0; i < i1; i++) {
+    const uint32_t m = tree->wrec[i].meta;
+    const int d = tree->wrec[i].dof_idx;
+    if ((m & 17u) == 17u) orow[3 * (m >> 24)] = drow[d];
+  }
+  float cpx, cpy, cpz;
+  f4 crot;
+  {
+    const FkBodyRec r0 = tree->wrec[i0];           // body 0 opens every list
+    const float px = root_pos[fc * 3], py = root_pos[fc * 3 + 1], pz = root_pos[fc * 3 + 2];
+    const f4 rot = {root_rot[fc * 4], root_rot[fc * 4 + 1], root_rot[fc * 4 + 2], root_rot[fc * 4 + 3]};
+    cpx = px; cpy = py; cpz = pz; crot = rot;
+    const int dst = (int)((r0.meta >> 16) & 255u) - 1;
+    if (dst >= 0) {
+      float* sl = stk + dst * 7 * 64;
+      sl[0] = px; sl[64] = py; sl[128] = pz; sl[192] = rot.x; sl[256] = rot.y; sl[320] = rot.z; sl[384] = rot.w;
+    }
+    if (r0.meta & 16u) {
+      orow[0] = px; orow[1] = py; orow[2] = pz;
+      if (body_rot) { rrow_p[0] = rot.x; rrow_p[1] = rot.y; rrow_p[2] = rot.z; rrow_p[3] = rot.w; }
+      if (on) zmin = pz;
+    }
+  }
+  FkBodyRec nxt = tree->wrec[i0 + 1 < i1 ? i0 + 1 : i0];
+  for (int i = i0 + 1; i < i1; i++) {
+    const FkBodyRec cur = nxt;                     // one 64-byte scalar load per body, issued one body ahead
+    nxt = tree->wrec[i + 1 < i1 ? i + 1 : i];
+    const int j = (int)(cur.meta >> 24);
+    const int src = (int)((cur.meta >> 8) & 255u) - 1, dst = (int)((cur.meta >> 16) & 255u) - 1;
+    const bool own = cur.meta & 16u;
+    float ang = 0.0f;
+    if (cur.meta & 1u) ang = own ? orow[3 * j] : drow[cur.dof_idx];    // (an ancestor another wavefront stores: read directly)
+    float ppx = cpx, ppy = cpy, ppz = cpz;
+    f4 prot = crot;
+    if (src >= 0) {                                // wave-uniform: the parent is not the body walked just before
+      const float* par = stk + src * 7 * 64;
+      ppx = par[0]; ppy = par[64]; ppz = par[128];
+      prot = f4{par[192], par[256], par[320], par[384]};
+    }
+    float wx, wy, wz;
+    f4 rot;
+    fk_body(cur, ang, prot, wx, wy, wz, rot);
+    const float px = ppx + wx, py = ppy + wy, pz = ppz + wz;
+    cpx = px; cpy = py; cpz = pz; crot = rot;
+    if (dst >= 0) {
+      float* sl = stk + dst * 7 * 64;
+      sl[0] = px; sl[64] = py; sl[128] = pz; sl[192] = rot.x; sl[256] = rot.y; sl[320] = rot.z; sl[384] = rot.w;
+    }
+    if (own) {
+      float* o = orow + 3 * j;
+      o[0] = px; o[1] = py; o[2] = pz;
+      if (body_rot) { float* r = rrow_p + 4 * j; r[0] = rot.x; r[1] = rot.y; r[2] = rot.z; r[3] = rot.w; }
+      if (on) zmin = fminf(zmin, pz);
+    }
+  }
+  __syncthreads();
+  // the block's output is one contiguous range of body_pos (and body_rot): all wavefronts stream it out, 16 B per lane
+  const int nthr = 64 * nwave, t = threadIdx.x;
+  const long long f0 = (long long)blockIdx.x * 64;
+  const long long nfr = (B - f0) < 64 ? (B - f0) : 64;
+  {
+    const int nfloat = (int)(nfr * row), nvec = nfloat >> 2;
+    float* gdst = body_pos + f0 * row;
+    const float4* sv = reinterpret_cast<const float4*>(outb);
+    float4* dv = reinterpret_cast<float4*>(gdst);
+    int i = t;
+    for (; i + 3 * nthr < nvec; i += 4 * nthr) {
+      const float4 a0 = sv[i], a1 = sv[i + nthr], a2 = sv[i + 2 * nthr], a3 = sv[i + 3 * nthr];
+      dv[i] = a0; dv[i + nthr] = a1; dv[i + 2 * nthr] = a2; dv[i + 3 * nthr] = a3;
+    }
+    for (; i < nvec; i += nthr) dv[i] = sv[i];
+    for (int e = (nvec << 2) + t; e < nfloat; e += nthr) gdst[e] = outb[e];
+  }
+  if (body_rot) {
+    float4* rdst = reinterpret_cast<float4*>(body_rot + f0 * rrow);
+    const int nrv = (int)(nfr * nb);
+    const float4* sv = reinterpret_cast<const float4*>(outr);
+    int i = t;
+    for (; i + 3 * nthr < nrv; i += 4 * nthr) {
+      const float4 a0 = sv[i], a1 = sv[i + nthr], a2 = sv[i + 2 * nthr], a3 = sv[i + 3 * nthr];
+      rdst[i] = a0; rdst[i + nthr] = a1; rdst[i + 2 * nthr] = a2; rdst[i + 3 * nthr] = a3;
+    }
+    for (; i < nrv; i += nthr) rdst[i] = sv[i];
+  }
+  if (min_part) {
+    for (int off = 32; off > 0; off >>= 1) zmin = fminf(zmin, __shfl_xor(zmin, off, 64));
+    if (tid == 0) red[wave] = zmin;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float m = red[0];
+      for (int w = 1; w < nwave; w++) m = fminf(m, red[w]);
+      min_part[blockIdx.x] = m;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void min_reduce_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
   __shared__ float red[4];
   float z = INFINITY;
@@ -276,6 +415,9 @@ static hipError_t fk_opt_in_large_lds() {
   if (dev < 64 && ((done_mask >> dev) & 1ull)) return hipSuccess;
   e = hipFuncSetAttribute(reinterpret_cast<const void*>(gmr::fk_batch_kernel<true>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gmr::fk_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024 - 1024);
   if (e == hipSuccess && dev < 64) __atomic_fetch_or(&done_mask, 1ull << dev, __ATOMIC_RELAXED);
   return e;
 }
@@ -302,7 +444,12 @@ extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree* d_tree, const gmr::
       smem = (size_t)nslot * 7 * gmr::FK_BLOCK * sizeof(float);
     }
   }
-  if (staged)
+  // several wavefronts per block when the tree splits (gmr_fk_create) and the slots of the split walk fit beside the staging area
+  const size_t smem_split = (size_t)h_tree->nslot_split * 7 * 64 * sizeof(float) + stage_bytes;
+  if (staged && h_tree->nwave > 1 && smem_split <= 160 * 1024 - 8192 && (smem_split <= 64 * 1024 || fk_opt_in_large_lds() == hipSuccess))
+    hipLaunchKernelGGL(gmr::fk_split_kernel, dim3(blocks), dim3(64 * h_tree->nwave), smem_split, stream, d_tree, B,
+                       d_root_pos, d_root_rot, d_dof, d_body_pos, d_body_rot, d_min_z ? d_min_part : nullptr);
+  else if (staged)
     hipLaunchKernelGGL(gmr::fk_batch_kernel<true>, dim3(blocks), dim3(gmr::FK_BLOCK), smem, stream, d_tree, B,
                        d_root_pos, d_root_rot, d_dof, d_body_pos, d_body_rot, d_min_z ? d_min_part : nullptr);
   else

@@ -6,12 +6,13 @@ namespace gmr {
 
 constexpr int FK_MAX_BODIES = 64;
 constexpr int FK_MAX_DEPTH = 24;
+constexpr int FK_MAX_WAVES = 4;
 
 // Everything the walk needs about one body, as ONE 64-byte record: a single s_load_dwordx16 per body, issued one
 // body ahead (the per-field arrays cost four dependent scalar / vector round trips per body).
 struct FkBodyRec {
   float t[3];                 // local translation
-  uint32_t meta;              // [7:0] has a hinge, [15:8] load slot + 1 (0: parent = previous body), [23:16] save slot + 1, [31:24] parent
+  uint32_t meta;              // [0] has a hinge, [15:8] load slot + 1 (0: parent = previous body), [23:16] save slot + 1, [31:24] parent
   float r[4];                 // local rotation xyzw, un-normalised
   double axis[3];             // normalised hinge axis (float64)
   int32_t dof_idx;            // first dof of the joint or -1
@@ -32,6 +33,88 @@ struct FkTree {
   float local_r[FK_MAX_BODIES * 4];            // xyzw, un-normalised (kinematics_model.py:119-123)
   double axis[FK_MAX_BODIES * 3];              // float64 hinge axis (kinematics_model.py:133-134)
   FkBodyRec rec[FK_MAX_BODIES];                // the same data, one record per body
+  // The split walk (fk_split_kernel): up to FK_MAX_WAVES wavefronts per block of 64 frames, each walking a part of the
+  // tree -- the chain of ancestors its subtrees hang from (recomputed by every wavefront that needs it) and then its
+  // own subtrees.  wrec[wave_start[w] .. wave_start[w + 1]) is wavefront w's list in body order; in these records
+  // meta[4] = this wavefront stores the body's outputs, meta[15:8] / [23:16] = load / save slot + 1 in the block-wide
+  // slot numbering (slots hold position and rotation), meta[31:24] = the body.
+  int nwave, nslot_split;
+  int wave_start[5];
+  FkBodyRec wrec[2 * FK_MAX_BODIES];
 };
+
+// Partition of the tree for the split walk (host side, gmr_fk_create).  `parent[b] < b`.  Returns the number of
+// wavefronts (1: not worth splitting) and fills, per wavefront, the ascending list of bodies it walks.
+inline int fk_split_tree(int nbody, const int* parent, int maxw, int lists[][FK_MAX_BODIES], int* nlist) {
+  int size[FK_MAX_BODIES], nchild[FK_MAX_BODIES] = {0};
+  for (int b = 0; b < nbody; b++) size[b] = 1;
+  for (int b = nbody - 1; b >= 1; b--) { size[parent[b]] += size[b]; nchild[parent[b]]++; }
+  bool trunk[FK_MAX_BODIES] = {false}, part[FK_MAX_BODIES] = {false};
+  trunk[0] = true;
+  for (int b = 1; b < nbody; b++) if (parent[b] == 0) part[b] = true;
+  int bin_of[FK_MAX_BODIES];
+  auto evaluate = [&](const bool* tr, const bool* pt, int* bins) {
+    // longest-processing-time assignment of the parts; a bin also walks the trunk ancestors of its parts
+    int order[FK_MAX_BODIES], n = 0;
+    for (int b = 0; b < nbody; b++) if (pt[b]) order[n++] = b;
+    for (int i = 1; i < n; i++) for (int j = i; j > 0 && size[order[j]] > size[order[j - 1]]; j--) { int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    int cost[FK_MAX_WAVES] = {0};
+    bool anc[FK_MAX_WAVES][FK_MAX_BODIES] = {};
+    for (int i = 0; i < n; i++) {
+      int best = 0, bestc = 1 << 30;
+      for (int w = 0; w < maxw; w++) {
+        int extra = 0;
+        for (int a = parent[order[i]]; a >= 0; a = a == 0 ? -1 : parent[a]) if (!anc[w][a]) extra++;
+        if (cost[w] + extra + size[order[i]] < bestc) { bestc = cost[w] + extra + size[order[i]]; best = w; }
+      }
+      for (int a = parent[order[i]]; a >= 0; a = a == 0 ? -1 : parent[a]) anc[best][a] = true;
+      cost[best] = bestc;
+      bins[order[i]] = best;
+    }
+    (void)tr;
+    int mx = 0;
+    for (int w = 0; w < maxw; w++) mx = cost[w] > mx ? cost[w] : mx;
+    return mx;
+  };
+  // open the largest part again and again (its top body joins the trunk, its children become parts) and keep the best
+  // configuration seen: a chain like waist yaw -> roll -> torso improves nothing until the limbs below it separate
+  int best = nbody > 1 ? evaluate(trunk, part, bin_of) : 1;
+  {
+    bool tr2[FK_MAX_BODIES], pt2[FK_MAX_BODIES];
+    for (int b = 0; b < nbody; b++) { tr2[b] = trunk[b]; pt2[b] = part[b]; }
+    for (int step = 0; step < nbody; step++) {
+      int r = -1;
+      for (int b = 1; b < nbody; b++) if (pt2[b] && nchild[b] > 0 && (r < 0 || size[b] > size[r])) r = b;
+      if (r < 0) break;
+      tr2[r] = true; pt2[r] = false;
+      for (int b = r + 1; b < nbody; b++) if (parent[b] == r) pt2[b] = true;
+      int bins2[FK_MAX_BODIES];
+      const int c = evaluate(tr2, pt2, bins2);
+      if (c < best) {
+        best = c;
+        for (int b = 0; b < nbody; b++) { trunk[b] = tr2[b]; part[b] = pt2[b]; bin_of[b] = bins2[b]; }
+      }
+    }
+  }
+  // a wavefront's list: ancestors of its parts and the parts' subtrees, ascending (parents come before children)
+  int nw = 0;
+  for (int w = 0; w < maxw; w++) {
+    bool in[FK_MAX_BODIES] = {false};
+    bool any = false;
+    for (int b = 1; b < nbody; b++) {
+      if (!(part[b] && bin_of[b] == w)) continue;
+      any = true;
+      for (int a = parent[b]; a >= 0; a = a == 0 ? -1 : parent[a]) in[a] = true;
+      in[b] = true;
+    }
+    if (!any) continue;
+    for (int b = 1; b < nbody; b++) if (!in[b] && !trunk[b] && in[parent[b]] && !part[b]) in[b] = true;   // descendants of a part
+    nlist[nw] = 0;
+    for (int b = 0; b < nbody; b++) if (in[b]) lists[nw][nlist[nw]++] = b;
+    nw++;
+  }
+  if (nw == 0) { nlist[0] = 0; for (int b = 0; b < nbody; b++) lists[0][nlist[0]++] = b; nw = 1; }
+  return nw;
+}
 
 }  // namespace gmr
