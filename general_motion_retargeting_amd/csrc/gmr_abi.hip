@@ -468,9 +468,13 @@ int gmr_fk_create(int nbody, const int32_t* parent, const float* local_t, const 
       const int n = nlist[w];
       int slot_of[gmr::FK_MAX_BODIES];
       for (int b = 0; b < nbody; b++) slot_of[b] = -1;
+      bool spare_used = false;                    // a wavefront's first parked parent lives in registers (slot code 254)
       for (int i = 1; i < n; i++) {               // a parent that is not the body walked just before is reloaded from a slot
         const int p = par[lists[w][i]];
-        if (lists[w][i - 1] != p && slot_of[p] < 0) slot_of[p] = nslot++;
+        if (lists[w][i - 1] != p && slot_of[p] < 0) {
+          if (!spare_used) { slot_of[p] = 254; spare_used = true; }
+          else slot_of[p] = nslot++;
+        }
       }
       for (int i = 0; i < n; i++) {
         const int b = lists[w][i];
@@ -486,7 +490,7 @@ int gmr_fk_create(int nbody, const int32_t* parent, const float* local_t, const 
     }
     t.wave_start[t.nwave] = nrec;
     for (int w = t.nwave + 1; w <= gmr::FK_MAX_WAVES; w++) t.wave_start[w] = nrec;
-    t.nslot_split = nslot > 0 ? nslot : 1;
+    t.nslot_split = nslot;
     for (int b = 0; b < nbody; b++) if (!owned[b]) { delete k; return fail(GMR_ERR_ARG, "split walk: body %d not covered", b); }
   }
   hipError_t e;

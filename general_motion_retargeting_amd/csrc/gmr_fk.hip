@@ -302,13 +302,16 @@ __global__ __launch_bounds__(64 * FK_MAX_WAVES) void fk_split_kernel(const FkTre
   }
   float cpx, cpy, cpz;
   f4 crot;
+  float spx = 0.0f, spy = 0.0f, spz = 0.0f;        // the wavefront's first parked parent stays in registers (slot code 254):
+  f4 srot = {0.0f, 0.0f, 0.0f, 1.0f};              // for the shipped trees no LDS slot is left, one more block fits a CU
   {
     const FkBodyRec r0 = tree->wrec[i0];           // body 0 opens every list
     const float px = root_pos[fc * 3], py = root_pos[fc * 3 + 1], pz = root_pos[fc * 3 + 2];
     const f4 rot = {root_rot[fc * 4], root_rot[fc * 4 + 1], root_rot[fc * 4 + 2], root_rot[fc * 4 + 3]};
     cpx = px; cpy = py; cpz = pz; crot = rot;
     const int dst = (int)((r0.meta >> 16) & 255u) - 1;
-    if (dst >= 0) {
+    if (dst == 254) { spx = px; spy = py; spz = pz; srot = rot; }
+    else if (dst >= 0) {
       float* sl = stk + dst * 7 * 64;
       sl[0] = px; sl[64] = py; sl[128] = pz; sl[192] = rot.x; sl[256] = rot.y; sl[320] = rot.z; sl[384] = rot.w;
     }
@@ -329,7 +332,8 @@ __global__ __launch_bounds__(64 * FK_MAX_WAVES) void fk_split_kernel(const FkTre
     if (cur.meta & 1u) ang = own ? orow[3 * j] : drow[cur.dof_idx];    // (an ancestor another wavefront stores: read directly)
     float ppx = cpx, ppy = cpy, ppz = cpz;
     f4 prot = crot;
-    if (src >= 0) {                                // wave-uniform: the parent is not the body walked just before
+    if (src == 254) { ppx = spx; ppy = spy; ppz = spz; prot = srot; }
+    else if (src >= 0) {                           // wave-uniform: the parent is not the body walked just before
       const float* par = stk + src * 7 * 64;
       ppx = par[0]; ppy = par[64]; ppz = par[128];
       prot = f4{par[192], par[256], par[320], par[384]};
@@ -339,7 +343,8 @@ __global__ __launch_bounds__(64 * FK_MAX_WAVES) void fk_split_kernel(const FkTre
     fk_body(cur, ang, prot, wx, wy, wz, rot);
     const float px = ppx + wx, py = ppy + wy, pz = ppz + wz;
     cpx = px; cpy = py; cpz = pz; crot = rot;
-    if (dst >= 0) {
+    if (dst == 254) { spx = px; spy = py; spz = pz; srot = rot; }
+    else if (dst >= 0) {
       float* sl = stk + dst * 7 * 64;
       sl[0] = px; sl[64] = py; sl[128] = pz; sl[192] = rot.x; sl[256] = rot.y; sl[320] = rot.z; sl[384] = rot.w;
     }
