@@ -325,6 +325,55 @@ __device__ __forceinline__ void se3_jlinv_aux5(const double e[6], const double a
   for (int i = 0; i < 9; i++) { A.a[i] = Am.a[i]; B.a[i] = -AQA.a[i]; }
 }
 
+// Column j of the same blocks, for three lanes per task (lane = 16 j + task): Ac = A e_j, Bc = B e_j with
+// A = skew(-w/2) + a w w^T + (1 - a t^2) I and B = -A Q A, Q = skew(sq) + c1 (rho w^T + w rho^T) + kw w w^T + dq I as in
+// se3_jlinv_aux5 -- but no matrix is ever formed: skew(u) x = u x x and (u v^T) x = u (v . x), so a column of B is
+// three matrix-vector products written as cross and dot products.  About half the instructions of the full blocks per
+// lane; values agree with them to rounding.
+__device__ __forceinline__ void se3_jlinv_col5(const double e[6], const double aux[5], int j, double Ac[3], double Bc[3]) {
+  const d3 rho = {e[0], e[1], e[2]}, w = {e[3], e[4], e[5]};
+  const d3 ej = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0};
+  const double t2 = dot(w, w);
+  Ac[0] = ej.x; Ac[1] = ej.y; Ac[2] = ej.z;
+  Bc[0] = Bc[1] = Bc[2] = 0.0;
+  if (t2 < 1e-10) return;
+  const double a = aux[0];
+  double c1, c2, c3;
+  if (t2 < 1e-2) {
+    c1 = 1.0 / 6.0 - t2 / 120.0 + t2 * t2 / 5040.0 - t2 * t2 * t2 / 362880.0;
+    c2 = -1.0 / 24.0 + t2 / 720.0 - t2 * t2 / 40320.0 + t2 * t2 * t2 / 3628800.0;
+    c3 = -1.0 / 120.0 + t2 / 5040.0 - t2 * t2 / 362880.0 + t2 * t2 * t2 / 39916800.0;
+  } else {
+    const double t = aux[3], it = aux[4], sn = aux[1], cs = aux[2];
+    const double it2 = it * it;
+    c1 = (t - sn) * it2 * it;
+    c2 = (1.0 - 0.5 * t2 - cs) * it2 * it2;
+    c3 = (t - sn - t2 * t / 6.0) * it2 * it2 * it;
+  }
+  const double c4 = -0.5 * (c2 - 3.0 * c3);
+  const double s = dot(w, rho);
+  const d3 n = cross(w, rho), m = cross(w, n);
+  const double k1 = (c1 + c2) * s;
+  const d3 sq = {0.5 * rho.x - k1 * w.x - c2 * m.x, 0.5 * rho.y - k1 * w.y - c2 * m.y, 0.5 * rho.z - k1 * w.z - c2 * m.z};
+  const double dq = -2.0 * c1 * s + 2.0 * c4 * s * t2, kw = -2.0 * c4 * s;
+  const double da = 1.0 - a * t2;
+  const d3 hw = {-0.5 * w.x, -0.5 * w.y, -0.5 * w.z};
+  // v = A e_j
+  const double awj = a * dot(w, ej);
+  const d3 hx = cross(hw, ej);
+  const d3 v = {hx.x + awj * w.x + da * ej.x, hx.y + awj * w.y + da * ej.y, hx.z + awj * w.z + da * ej.z};
+  // y = Q v
+  const double wv = dot(w, v), rv = dot(rho, v);
+  const double kr = c1 * wv, kq = c1 * rv + kw * wv;
+  const d3 sx = cross(sq, v);
+  const d3 y = {sx.x + kr * rho.x + kq * w.x + dq * v.x, sx.y + kr * rho.y + kq * w.y + dq * v.y, sx.z + kr * rho.z + kq * w.z + dq * v.z};
+  // z = A y
+  const double awy = a * dot(w, y);
+  const d3 hy = cross(hw, y);
+  Ac[0] = v.x; Ac[1] = v.y; Ac[2] = v.z;
+  Bc[0] = -(hy.x + awy * w.x + da * y.x); Bc[1] = -(hy.y + awy * w.y + da * y.y); Bc[2] = -(hy.z + awy * w.z + da * y.z);
+}
+
 // The lane id as a value the optimiser cannot see through.  Every predicate on the lane id (lane < nb, lane == pivot, ...)
 // is invariant for the whole kernel, so LLVM computes each ONCE at kernel entry and keeps its 64-bit mask in an SGPR
 // pair; a fully inlined frame loop has more than a hundred of them, they spill to VGPR lanes (v_writelane) and every

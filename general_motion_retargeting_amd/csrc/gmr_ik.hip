@@ -185,7 +185,8 @@ struct StageTabs {
   const short* pair_index; const uint2* items;      // 64-bit schedule items (gmr_ik_layout.h)
 };
 
-// (a) lane = task: M_k = -Jl^-1(e_k) (blocks -A, -B), weighted residual; returns the LM term mu
+// (a) lane = 16 j + task: column j of M_k = -Jl^-1(e_k) (blocks -A, -B; three lanes per task), weighted residual;
+// returns the LM term mu
 template <int NW, class LT>
 __device__ __forceinline__ double jlog_phase(const LT& L, double* sm, int stage, double lm_damping, int lane,
                                              Prof& pr) {
@@ -195,25 +196,28 @@ __device__ __forceinline__ double jlog_phase(const LT& L, double* sm, int stage,
   const double* wpos = sm + L.o.wpos[stage];
   const double* wrot = sm + L.o.wrot[stage];
   double mu = 0.0;
-  if (lane < K) {
-    const double* e = sm + L.o.e + 6 * lane;
+  const int k = lane & 15, j = lane >> 4;
+  if (k < K && j < 3) {
+    const double* e = sm + L.o.e + 6 * k;
     double ee[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ee[r] = e[r];
-    const double* ax = sm + L.o.eaux + 5 * lane;
+    const double* ax = sm + L.o.eaux + 5 * k;
     const double aux[5] = {ax[0], ax[1], ax[2], ax[3], ax[4]};
-    m3 A, B;
-    se3_jlinv_aux5(ee, aux, A, B);
-    double* M = sm + L.o.M + 18 * lane;
+    double Ac[3], Bc[3];
+    se3_jlinv_col5(ee, aux, j, Ac, Bc);
+    double* M = sm + L.o.M + 18 * k + j;
 #pragma unroll
-    for (int i = 0; i < 9; i++) { M[i] = -A.a[i]; M[9 + i] = -B.a[i]; }
-    double wp = wpos[lane], wr = wrot[lane];
-    double* we = sm + L.o.we + 6 * lane;
+    for (int i = 0; i < 3; i++) { M[3 * i] = -Ac[i]; M[9 + 3 * i] = -Bc[i]; }
+    if (j == 0) {
+      double wp = wpos[k], wr = wrot[k];
+      double* we = sm + L.o.we + 6 * k;
 #pragma unroll
-    for (int r = 0; r < 6; r++) {
-      double v = (r < 3 ? wp : wr) * ee[r];
-      we[r] = v;
-      mu += v * v;
+      for (int r = 0; r < 6; r++) {
+        double v = (r < 3 ? wp : wr) * ee[r];
+        we[r] = v;
+        mu += v * v;
+      }
     }
   }
   mu = lm_damping * row0_sum(mu);

@@ -694,3 +694,25 @@ def test_queued_dispatch_is_bit_identical_to_direct(hip, oracle, g1):
         assert np.array_equal(ref[1][s, :n], ns_o[0]) and np.abs(ref[0][s, :n] - q_o[0]).max() <= TOL_RAD
     with pytest.raises(hip.GmrHipError):
         sol.set_dispatch(-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src,robot", ALL_CONFIGS)
+def test_queued_dispatch_all_configs(hip, oracle, src, robot):
+    """Every shipped (source, robot) pair through the device-side queue: the bits of one workgroup per stream, and
+    the oracle's solve counts and angles on a sample."""
+    from general_motion_retargeting_amd import synth
+    su = get_setup(src, robot, 1.7)
+    nb, S, T = 24, 2600, 5                       # more streams than resident wavefronts (2 048 on an MI355X)
+    bh, bq = synth.make_streams(su.model, su.tt, nb, T, seed=9)
+    pick = np.arange(S) % nb
+    human, q0 = bh[pick].copy(), bq[pick].copy()
+    sol = hip.Solver(su.mb, su.ts)
+    sol.set_waves(1)
+    sol.set_dispatch(0)
+    q_d, ns_d, st_d = sol.retarget_streams(q0, human)
+    sol.set_dispatch(2)
+    q_q, ns_q, st_q = sol.retarget_streams(q0, human)
+    assert (st_d == 0).all() and np.array_equal(st_d, st_q) and np.array_equal(ns_d, ns_q) and np.array_equal(q_d, q_q)
+    q_o, ns_o, _ = oracle.retarget_streams(su.mb, su.ts, q0[:3], human[:3])
+    assert np.array_equal(ns_q[:3], ns_o) and np.abs(q_q[:3] - q_o).max() <= TOL_RAD

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Large-scale parity soak (measurement tool; may call the oracle like bench.py's cpu_baseline leg):
-every shipped (source, robot) config at S=2048 x T=64 on the GPU in the throughput shape, a random sample of
+every shipped (source, robot) config at S=2560 x T=64 on the GPU in the throughput shape (more streams than resident
+wavefronts: the queued dispatch), a random sample of
 96 streams per config re-computed by the CPU oracle; reports max joint / root deviation and solve-count
 mismatches; plus shard-invariance (the sample launched alone gives bit-identical results)."""
 import json
@@ -16,7 +17,7 @@ from general_motion_retargeting_amd import IK_CONFIG_DICT, GeneralMotionRetarget
 from oracle import oracle as orc  # noqa: E402
 
 orc.build()
-S, T, NS = 2048, 64, 96
+S, T, NS = 2560, 64, 96
 rng = np.random.default_rng(0)
 out = {}
 worst = 0.0
