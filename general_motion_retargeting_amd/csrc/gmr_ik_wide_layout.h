@@ -204,13 +204,24 @@ inline bool make_wide_schedule(const gmr_model_t& m, const gmr_taskset_t& ts, st
         ents.push_back({da, db, w, (uint32_t)(8 * o1) | ((uint32_t)(8 * o2) << 13)});
       }
     std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.w > y.w; });
-    std::vector<std::vector<Ent>> per_lane(64);
-    std::vector<int> load(64, 0);
-    for (const Ent& e : ents) {
-      int best = 0;
-      for (int l = 1; l < 64; l++) if (load[l] < load[best]) best = l;
-      per_lane[best].push_back(e);
-      load[best] += e.w + 1;
+    // A lane's cost is its number of terms (an entry's two stores ride on its last term).  The loop runs four slots per
+    // trip, so what counts is the smallest multiple of four every lane fits in: first-fit-decreasing bin packing into 64
+    // lanes of that capacity, the capacity raised until it works (G1: 1 014 terms -> 16 slots, the minimum).
+    std::vector<std::vector<Ent>> per_lane;
+    int total = 0;
+    for (const Ent& e : ents) total += e.w;
+    for (int cap = std::max(4, ((total + 63) / 64 + 3) & ~3);; cap += 4) {
+      per_lane.assign(64, {});
+      std::vector<int> load(64, 0);
+      bool fits = true;
+      for (const Ent& e : ents) {
+        int lane = -1;
+        for (int l = 0; l < 64 && lane < 0; l++) if (load[l] + e.w <= cap) lane = l;
+        if (lane < 0) { fits = false; break; }
+        per_lane[lane].push_back(e);
+        load[lane] += e.w;
+      }
+      if (fits) break;
     }
     int nt = 0;
     std::vector<std::vector<uint64_t>> li(64);
