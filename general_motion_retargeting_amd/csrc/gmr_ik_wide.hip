@@ -131,34 +131,31 @@ __device__ __forceinline__ double errors_wide(double* sm, uint32_t taskw, int K,
   return sqrt(ss);
 }
 
-// (a) lane = 16 j + task: column j of M_k = -Jl^-1(e_k) (three lanes per task); returns the LM term mu
+// (a) lane = task: M_k = -Jl^-1(e_k); returns the LM term mu.  (The three-lanes-per-task column form of the latency
+// kernel, se3_jlinv_col5, was measured here too: the same frames/s, 13 more registers -- 8 of them spilled to scratch.)
 __device__ __forceinline__ double jlog_wide(double* sm, const char* __restrict__ img, int stage, int K, double lm_damping,
                                             int lane, Prof& pr) {
   PROF_BEGIN(pr);
   double mu = 0.0;
-  const int k = lane & 15, j = lane >> 4;
-  if (k < K && j < 3) {
-    const double* e = sm + LD.e + 6 * k;
+  if (lane < K) {
+    const double* w = img_at<double>(img, IM.task[stage]) + 2 * lane;
+    const double wp = w[0], wr = w[1];
+    const double* e = sm + LD.e + 6 * lane;
     double ee[6];
 #pragma unroll
     for (int r = 0; r < 6; r++) ee[r] = e[r];
-    const double* ax = sm + LD.eaux + 5 * k;
+    const double* ax = sm + LD.eaux + 5 * lane;
     const double aux[5] = {ax[0], ax[1], ax[2], ax[3], ax[4]};
-    double Ac[3], Bc[3];
-    se3_jlinv_col5(ee, aux, j, Ac, Bc);
-    double* M = sm + LD.M + 18 * k + j;
+    m3 A, B;
+    se3_jlinv_aux5(ee, aux, A, B);
+    double* M = sm + LD.M + 18 * lane;
 #pragma unroll
-    for (int i = 0; i < 3; i++) { M[3 * i] = -Ac[i]; M[9 + 3 * i] = -Bc[i]; }
-  }
-  if (lane < K) {                                      // row 0: the task's weights and its share of the LM term
-    const double* w = img_at<double>(img, IM.task[stage]) + 2 * lane;
-    const double wp = w[0], wr = w[1];
+    for (int i = 0; i < 9; i++) { M[i] = -A.a[i]; M[9 + i] = -B.a[i]; }
     double* wt = sm + LD.wts + 2 * lane;
     wt[0] = wp; wt[1] = wr;
-    const double* e = sm + LD.e + 6 * lane;
 #pragma unroll
     for (int r = 0; r < 6; r++) {
-      double v = (r < 3 ? wp : wr) * e[r];
+      double v = (r < 3 ? wp : wr) * ee[r];
       mu += v * v;
     }
   }
