@@ -83,8 +83,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
   const double lo = row ? los[dof] : 0.0, hi = row ? his[dof] : 0.0;
   const double ci = row ? (sm + L.o.c)[dof] : 0.0;
   const double* Hrow = H + (row ? dof : 0) * ldh;
-  double cabs = lane_in < n ? fabs((sm + L.o.c)[lane_in]) : 0.0;
-  const double dual_tol = 1e-13 * (1.0 + rows3_max(cabs));
+  double dual_tol = -1.0;                                      // 1e-13 (1 + max |c|): computed when a multiplier is first checked
   const double ptol_lo = 1e-12 * (1.0 + fabs(lo)), ptol_hi = 1e-12 * (1.0 + fabs(hi));
   // column dofs of the local matrix (wave-uniform): limb columns then trunk columns
   int cdof[TR_NV];
@@ -285,6 +284,10 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
     // ---- (6) violated bounds (free set) / multipliers (fixed set): g = H x + c ---------------------
     if (fixedm != 0ull) {                                     // multipliers need the whole x
       if (own) xs[dof] = x;
+      if (dual_tol < 0.0) {                                   // (wave-uniform; most solves never fix a variable)
+        const int li = fresh_lane(lane_in);
+        dual_tol = 1e-13 * (1.0 + rows3_max(li < n ? fabs((sm + L.o.c)[li]) : 0.0));
+      }
       TR_SYNC();                                                                             // B2
     }
     PROF_END(pr, PH_MULT);

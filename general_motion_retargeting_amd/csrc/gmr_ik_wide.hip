@@ -329,8 +329,7 @@ __device__ __forceinline__ int solve_rows(const WideDims& D, double* sm, const c
   const double ci = row ? (sm + LD.c)[dof] : 0.0;
   const double* LMrow = H + 7 * lane_in;                      // D_g row a (limb lanes) / B_g row t (trunk lanes)
   const double* Trow = H + WD_HT + NT * (is_trunk ? t : 0);
-  const double cabs = lane_in < D.nv ? fabs((sm + LD.c)[lane_in]) : 0.0;
-  const double dual_tol = 1e-13 * (1.0 + rows3_max(cabs));
+  double dual_tol = -1.0;                                     // 1e-13 (1 + max |c|): computed when a multiplier is first checked
   const double ptol_lo = 1e-12 * (1.0 + fabs(lo)), ptol_hi = 1e-12 * (1.0 + fabs(hi));
   const unsigned long long absent = __ballot(!row);           // rows without a variable (short limbs / trunk)
 
@@ -549,6 +548,7 @@ __device__ __forceinline__ int solve_rows(const WideDims& D, double* sm, const c
     }
     // ---- (6) violated bounds (free set) / multipliers (fixed set): g = H x + c ---------------------
     if (fixedm != 0ull) {                                     // multipliers need the whole x, by owner lane
+      if (dual_tol < 0.0) dual_tol = 1e-13 * (1.0 + rows3_max(lane_in < D.nv ? fabs((sm + LD.c)[lane_in]) : 0.0));   // (wave-uniform)
       if (is_limb || grp == 0) xl[lane_in] = row ? x : 0.0;
       wsync();                                                                               // B2
     }
