@@ -310,14 +310,21 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
     // each violating owner lane sets its dof's bit in the round's set (LDS atomic OR: order-independent)
     if (newst != 0) atomicOr(&vcur[newst - 1], 1ull << dof);
     if (fresh_lane(lane0) == 0 && tbad) atomicOr(&vcur[3], 1ull);
+    // With no variable fixed nobody reads xs in this round (no multipliers): a lane without a violation stores its
+    // result now, and if the round turns out to be the last one, B3 has already published it -- one barrier less per
+    // solve on the common path.  (A violating lane's round is not the last; its store would be overwritten anyway.)
+    const bool early = fixedm == 0ull;                        // wave- and workgroup-uniform
+    if (early && own && newst == 0) xs[dof] = fmin(fmax(x, lo), hi);
     TR_SYNC();                                                                               // B3
     PROF_END(pr, PH_IO);
     const unsigned long long to_lo = vcur[0], to_up = vcur[1], rel = vcur[2];
     if (vcur[3]) return GMR_STATUS_QP_FAILED;
     const unsigned long long all = to_lo | to_up | rel;
     if (all == 0ull) {
-      if (own) xs[dof] = fmin(fmax(x, lo), hi);
-      TR_SYNC();
+      if (!early) {
+        if (own) xs[dof] = fmin(fmax(x, lo), hi);
+        TR_SYNC();
+      }
       return GMR_STATUS_OK;
     }
     const int total = __popcll(all);
