@@ -880,6 +880,7 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
       preprocess_wave<NW>(L, sm, is_foot, human_root, prm[4], flags, lane, pr);
       if (tgt_out)     // the poses handed to task.set_target (motion_retarget.py:117-136) = scaled_human_data
         for (int i = lane; i < (int)fstride; i += 64) tgt_out[f * fstride + i] = (sm + L.o.tgt)[i];
+      double last_E = -1.0;                          // the stage's last residual norm (at the current configuration)
       for (int stage = 0; stage < 2; stage++) {
         if (!(stage == 0 ? use0 : use1) || (flags & GMR_FLAG_EVAL_ONLY)) continue;
         const StageTabs tb = {si + L.o.i_task_body[stage], si + L.o.i_task_human[stage], si + L.o.i_pair_task[stage],
@@ -900,7 +901,10 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
           epoch++;
           __syncthreads();
         }
-        double curr = errors_wave<NW>(L, sm, tb.task_body, tb.task_human, K, lane, pr);
+        // (same task list in both tables: the first stage's last evaluation is this stage's first, and its residuals
+        //  and log-map terms are still in LDS for the Jl^-1 phase)
+        double curr = (stage == 1 && (use1 & 2) && last_E >= 0.0) ? last_E
+                                                                 : errors_wave<NW>(L, sm, tb.task_body, tb.task_human, K, lane, pr);
         int nsol = 0, num_iter = 0;
         for (;;) {
           build_qp_main<NW>(L, sm, stage, tb, hinge_body, limited, ctl, epoch, prm[0], prm[1], prm[3], lane, pr);
@@ -926,6 +930,7 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
             __syncthreads();
           }
           double next = errors_wave<NW>(L, sm, tb.task_body, tb.task_human, K, lane, pr);
+          last_E = next;
           nsol++;
           if (nsol > 1) num_iter++;
           if (!(curr - next > prm[2] && num_iter < max_iter)) break;

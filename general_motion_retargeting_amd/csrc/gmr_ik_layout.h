@@ -388,6 +388,13 @@ inline IkParams make_ik_params(const gmr_model_t& m, const gmr_taskset_t& ts) {
   p.damping = ts.damping; p.lm_damping = ts.lm_damping; p.tol = ts.tol; p.limit_gain = ts.limit_gain;
   p.ground_offset = ts.ground_offset; p.dt = m.timestep;
   p.max_iter = ts.max_iter; p.human_root = ts.human_root; p.use0 = ts.use_stage[0]; p.use1 = ts.use_stage[1];
+  // Both tables name the same (robot body, human body) tasks in the same order -- every shipped config: the unweighted
+  // residual norm the second stage starts from IS the one the first stage ended with (bit for bit), so the kernels
+  // skip that evaluation.  Carried as bit 1 of use1.
+  bool same = ts.use_stage[0] && ts.use_stage[1] && ts.ntask[0] == ts.ntask[1];
+  for (int k = 0; same && k < ts.ntask[0]; k++)
+    same = ts.task_body[0][k] == ts.task_body[1][k] && ts.task_human[0][k] == ts.task_human[1][k];
+  if (same) p.use1 |= 2;
   return p;
 }
 

@@ -803,11 +803,14 @@ __global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(
       preprocess_wide(D, sm, img, human_root, prm[4], flags, lane, pr);
       if (tgt_out)     // the poses handed to task.set_target (motion_retarget.py:117-136) = scaled_human_data
         for (int i = lane; i < (int)fstride; i += 64) tgt_out[f * fstride + i] = (sm + LD.tgt)[i];
+      double last_E = -1.0;                          // the stage's last residual norm (at the current configuration)
       for (int stage = 0; stage < 2; stage++) {
         if (!(stage == 0 ? use0 : use1) || (flags & GMR_FLAG_EVAL_ONLY)) continue;
         const int K = D.K[stage];
         const uint32_t taskw = lane < K ? img_at<uint32_t>(img, IM.taski[stage])[lane] : 0u;
-        double curr = errors_wide(sm, taskw, K, lane, pr);
+        // (same task list in both tables -- bit 1 of use1, gmr_ik_layout.h: the first stage's last evaluation is this
+        //  stage's first, and its residuals and log-map terms are still in LDS for the Jl^-1 phase)
+        double curr = (stage == 1 && (use1 & 2) && last_E >= 0.0) ? last_E : errors_wide(sm, taskw, K, lane, pr);
         int nsol = 0, num_iter = 0;
         for (;;) {
           const double mu = jlog_wide(sm, img, stage, K, prm[1], lane, pr);
@@ -830,6 +833,7 @@ __global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(
           integrate_wide(D, sm, prm[5], lane, pr);
           fk_wide(D, sm, img, lane, pr);
           const double next = errors_wide(sm, taskw, K, lane, pr);
+          last_E = next;
           nsol++;
           if (nsol > 1) num_iter++;
           if (!(curr - next > prm[2] && num_iter < max_iter)) break;
