@@ -896,7 +896,7 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
         }
         // every residual evaluation is preceded by a kick of the helpers: they turn the FK state into the body
         // Jacobians of this stage's (task, dof) pairs while this wavefront evaluates residuals and Jl^-1
-        if (NW > 1) {
+        if (NW > 1 && !(stage == 1 && (use1 & 4) && last_E >= 0.0)) {   // (same pairs: the first stage's last kick still holds)
           if (lane == 0) { int* c = ctl + 2 * (epoch & 1); c[0] = CMD_JBODY; c[1] = stage; }
           epoch++;
           __syncthreads();

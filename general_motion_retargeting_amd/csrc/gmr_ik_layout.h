@@ -395,6 +395,12 @@ inline IkParams make_ik_params(const gmr_model_t& m, const gmr_taskset_t& ts) {
   for (int k = 0; same && k < ts.ntask[0]; k++)
     same = ts.task_body[0][k] == ts.task_body[1][k] && ts.task_human[0][k] == ts.task_human[1][k];
   if (same) p.use1 |= 2;
+  // ... and the same (task, dof) pairs: the body Jacobians the helpers produced after the first stage's last FK are the
+  // second stage's too (bit 2)
+  bool same_pairs = same && ts.npair[0] == ts.npair[1];
+  for (int i = 0; same_pairs && i < ts.npair[0]; i++)
+    same_pairs = ts.pair_task[0][i] == ts.pair_task[1][i] && ts.pair_dof[0][i] == ts.pair_dof[1][i];
+  if (same_pairs) p.use1 |= 4;
   return p;
 }
 
