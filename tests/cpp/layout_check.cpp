@@ -132,7 +132,14 @@ int main(int argc, char** argv) {
     }
     lds[nw == 4] = L.smem_bytes; nd[nw == 4] = L.o.n_double; nwd[nw == 4] = (L.smem_bytes - L.o.n_double * 8 - L.o.n_short * 2) / 4;
   }
-  std::printf("ok nv=%d tree=%d limbs=%d trunk=%d lds1=%d (%d doubles, %d words) lds4=%d (%d doubles, %d words)\n", nv, (int)tr.ok, nlimb, tr.nt,
-              lds[0], nd[0], nwd[0], lds[1], nd[1], nwd[1]);
+  // stage flags: bit 1 of use1 = both tables name the same tasks, bit 2 = and the same (task, dof) pairs
+  const gmr::IkParams prm = gmr::make_ik_params(m, ts);
+  bool same = ts.use_stage[0] && ts.use_stage[1] && ts.ntask[0] == ts.ntask[1];
+  for (int k = 0; same && k < ts.ntask[0]; k++) same = ts.task_body[0][k] == ts.task_body[1][k] && ts.task_human[0][k] == ts.task_human[1][k];
+  CHECK(((prm.use1 & 2) != 0) == same, "same-task flag");
+  CHECK(!(prm.use1 & 4) || (prm.use1 & 2), "same pairs imply same tasks");
+  CHECK((prm.use1 != 0) == (ts.use_stage[1] != 0) && prm.use0 == ts.use_stage[0], "stage switches");
+  std::printf("ok nv=%d tree=%d limbs=%d trunk=%d lds1=%d (%d doubles, %d words) lds4=%d (%d doubles, %d words) use1=%d\n", nv, (int)tr.ok, nlimb, tr.nt,
+              lds[0], nd[0], nwd[0], lds[1], nd[1], nwd[1], prm.use1);
   return 0;
 }
