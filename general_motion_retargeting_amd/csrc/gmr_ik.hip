@@ -277,6 +277,7 @@ __device__ __forceinline__ void pairs_phase(const LT& L, double* sm, int stage, 
     cpart[p] = cp;   // this column's contribution to c = sum_k (W J_k)^T (W e_k)
   }
   if (vlane < 6) Jw[6 * L.o.cap.p + vlane] = 0.0;   // the row that schedule items without a term read
+  if (vlane == 6) cpart[L.o.cap.p] = 0.0;           // and the c share absent (task, dof) pairs gather
 }
 
 // (b1) 4-wavefront shape, helpers only, right after the FK and concurrently with the main wavefront's residual
@@ -342,6 +343,7 @@ __device__ __forceinline__ void pairs_from_jbody(const LT& L, double* sm, int st
     cpart[p] = cp;
   }
   if (vlane < 6) Jw[6 * L.o.cap.p + vlane] = 0.0;   // the row that schedule items without a term read
+  if (vlane == 6) cpart[L.o.cap.p] = 0.0;           // and the c share absent (task, dof) pairs gather
 }
 
 // (c) lane = dof: gather c; bounds of the limited hinges (mink ConfigurationLimit)
@@ -349,15 +351,16 @@ template <class LT>
 __device__ __forceinline__ void cvec_phase(const LT& L, double* sm, int stage, const StageTabs& tb,
                                            const short* limited, double limit_gain, int lane) {
   lane = fresh_lane(lane);
-  const int K = L.K[stage], nv = L.nv;
-  const double* cpart = sm + L.o.cpart;
+  const int nv = L.nv;
+  const char* cpart = reinterpret_cast<const char*>(sm + L.o.cpart);
   if (lane < nv) {
-    int idx[GMR_MAX_TASKS];
+    // the table holds byte offsets into cpart; absent pairs and absent tasks name its zero slot: no compare, no select
+    int off[GMR_MAX_TASKS];
 #pragma unroll
-    for (int k = 0; k < GMR_MAX_TASKS; k++) idx[k] = k < K ? (int)tb.pair_index[k * L.o.nvp + lane] : -1;
+    for (int k = 0; k < GMR_MAX_TASKS; k++) off[k] = (unsigned short)tb.pair_index[k * L.o.nvp + lane];
     double cc = 0.0;
 #pragma unroll
-    for (int k = 0; k < GMR_MAX_TASKS; k++) cc += idx[k] >= 0 ? cpart[idx[k]] : 0.0;
+    for (int k = 0; k < GMR_MAX_TASKS; k++) cc += *reinterpret_cast<const double*>(cpart + off[k]);
     (sm + L.o.c)[lane] = cc;
     double lo = -INFINITY, hi = INFINITY;
     if (lane >= 6 && limited[lane - 6]) {

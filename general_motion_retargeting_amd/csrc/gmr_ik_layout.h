@@ -70,7 +70,7 @@ constexpr IkOffsets ik_offsets(int nvp, int nw) {
   L.raw = L.M;                                     // the raw frame is consumed by the preprocess step, before any solve
   if (o & 1) o++;                                  // Jw rows (48 B) are read as three 16-B pieces
   L.Jw = o; o += ik_max(6 * (cp.p + 1), 7 * cp.nb + 1);   // row cap.p stays zero: what items without a term read
-  L.cpart = o; o += cp.p;
+  L.cpart = o; o += cp.p + 1;                      // slot cap.p stays zero: the share of an absent (task, dof) pair
   L.xb = L.Jw;                                     // FK runs between solves, when the assembly scratch is dead
   // The transpose scratch of the QP solvers (dense: nvp x (nvp+1); tree: 4 x 18 x 19) is only live inside a
   // solve, when the assembly scratch [e, eaux, we, M, Jw, cpart] is dead: alias it there.
@@ -451,12 +451,15 @@ inline std::vector<char> make_ik_image(const gmr_model_t& m, const gmr_taskset_t
   for (int s = 0; s < 2; s++) {
     uint32_t* dst = L.g_items[s] >= 0 ? reinterpret_cast<uint32_t*>(img.data()) + L.g_items[s] : sw + L.w_items[s];
     std::memcpy(dst, sch.padded[s].data(), sch.padded[s].size() * 8);
+    for (int k = 0; k < L.o.cap.k; k++)
+      for (int d = 0; d < L.nvp; d++) si[L.o.i_pair_index[s] + k * L.nvp + d] = (short)(8 * L.o.cap.p);
     for (int k = 0; k < L.K[s]; k++) {
       si[L.o.i_task_body[s] + k] = (short)ts.task_body[s][k];
       si[L.o.i_task_human[s] + k] = (short)ts.task_human[s][k];
       sm[L.o.wpos[s] + k] = ts.w_pos[s][k];
       sm[L.o.wrot[s] + k] = ts.w_rot[s][k];
-      for (int d = 0; d < nv; d++) si[L.o.i_pair_index[s] + k * L.nvp + d] = (short)ts.pair_index[s][k][d];
+      // (byte offset of the pair's c share in cpart; absent pairs -- and, below, absent tasks -- name the zero slot)
+      for (int d = 0; d < nv; d++) si[L.o.i_pair_index[s] + k * L.nvp + d] = (short)(8 * (ts.pair_index[s][k][d] >= 0 ? ts.pair_index[s][k][d] : L.o.cap.p));
     }
     // per (task, dof) pair, everything the Jacobian-column phase looks up, packed so that it is two
     // independent 16-bit reads instead of a chain of four: [3:0] task, [9:4] dof, [15:10] task body; hinge body
