@@ -716,3 +716,31 @@ def test_queued_dispatch_all_configs(hip, oracle, src, robot):
     assert (st_d == 0).all() and np.array_equal(st_d, st_q) and np.array_equal(ns_d, ns_q) and np.array_equal(q_d, q_q)
     q_o, ns_o, _ = oracle.retarget_streams(su.mb, su.ts, q0[:3], human[:3])
     assert np.array_equal(ns_q[:3], ns_o) and np.abs(q_q[:3] - q_o).max() <= TOL_RAD
+
+
+@pytest.mark.gpu
+def test_fk_split_walk_is_bit_equal_to_one_wavefront_per_block(hip, monkeypatch):
+    """Every loadable robot tree: the split walk (up to four wavefronts per 64-frame block, ancestors recomputed)
+    gives the bits of the one-wavefront walk, positions and rotations, for every number of wavefronts."""
+    from general_motion_retargeting_amd import params
+    from general_motion_retargeting_amd.models import load_kinematics_tree
+    rng = np.random.default_rng(3)
+    for robot, xml in params.ROBOT_XML_DICT.items():
+        try:
+            tree = load_kinematics_tree(xml)
+        except AssertionError:
+            continue
+        B = 777
+        monkeypatch.setenv("GMR_FK_WAVES", "1")
+        fk1 = hip.FkHandle(tree)
+        dof = rng.uniform(-1.5, 1.5, size=(B, fk1.ndof)).astype(np.float32)
+        rp = rng.normal(size=(B, 3)).astype(np.float32)
+        rq = rng.normal(size=(B, 4)); rq = (rq / np.linalg.norm(rq, axis=1, keepdims=True)).astype(np.float32)
+        bp1, br1, mz1 = fk1.fk(rp, rq, dof, want_min_z=True)
+        for waves in ("2", "3", "4"):
+            monkeypatch.setenv("GMR_FK_WAVES", waves)
+            fkn = hip.FkHandle(tree)
+            bp, br, mz = fkn.fk(rp, rq, dof, want_min_z=True)
+            assert np.array_equal(bp, bp1) and np.array_equal(br, br1) and mz == mz1, (robot, waves)
+            bp_only, none, _ = fkn.fk(rp, rq, dof, want_rot=False)
+            assert none is None and np.array_equal(bp_only, bp1), (robot, waves)
