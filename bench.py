@@ -44,6 +44,19 @@ from general_motion_retargeting_amd.models import load_ik_config, load_robot  # 
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (spec sheet)
+def _wide_roofline(robot, frames, solves_per_frame, seconds):
+    """HBM and FP64-VALU fractions of the throughput kernel over one step of the 1M-frame leg (wall clock of the step:
+    queue initialisation + kernel), same accounting as the headline's `roofline`."""
+    nsolve = solves_per_frame * frames
+    flops = nsolve * F_ITER_DENSE.get(robot, 1.77e5) + (nsolve + 2 * frames) * F_ERR.get(robot, 2.1e3)
+    gbs = BYTES_PER_FRAME.get(robot, 1360) * frames / seconds / 1e9
+    return {"kernel": "ik_wide_kernel (queued dispatch)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": BYTES_PER_FRAME.get(robot, 1360),
+            "fp64_valu": {"achieved_tflops": flops / seconds / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                          "frac": flops / seconds / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                          "flops_model": "SURVEY.md 8(d) dense accounting, measured solve counts"}}
+
+
 # SURVEY.md 8(d), G1: algorithmic bytes and flops
 BYTES_PER_FRAME = {"unitree_g1": 1360}
 F_ITER_DENSE = {"unitree_g1": 1.77e5}
@@ -241,6 +254,7 @@ def main():
                                 f"(the batch `--gpus N` shards; throughput shape: one wavefront per stream)",
                     "value": sres["value"], "unit": "frames/s", "steps": sres["steps"],
                     "ms_per_step": sres["seconds"] / sres["steps"] * 1e3, "mean_solves_per_frame": sres["mean_solves_per_frame"],
+                    "roofline": _wide_roofline(args.robot, SS * ST, sres["mean_solves_per_frame"], sres["seconds"] / sres["steps"]),
                 }
         else:
             out.update({
