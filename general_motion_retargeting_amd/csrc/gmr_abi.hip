@@ -190,7 +190,7 @@ static int validate(const gmr_model_t* m, const gmr_taskset_t* t) {
       if (t->task_human[s][k] < 0 || t->task_human[s][k] >= t->nhuman) return fail(GMR_ERR_ARG, "task human invalid");
       if (t->task_col0[s][k] != p) return fail(GMR_ERR_ARG, "task_col0 not contiguous");
       int n = t->task_ncol[s][k];
-      if (n < 6 || p + n > t->npair[s]) return fail(GMR_ERR_ARG, "task_ncol invalid");
+      if (n < 3 || p + n > t->npair[s]) return fail(GMR_ERR_ARG, "task_ncol invalid");   // (base translations may be pruned)
       for (int c = 0; c < n; c++) {
         int d = t->pair_dof[s][p + c];
         if (t->pair_task[s][p + c] != k || d < 0 || d >= m->nv) return fail(GMR_ERR_ARG, "pair table invalid");

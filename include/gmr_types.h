@@ -70,7 +70,7 @@ typedef struct gmr_taskset_t {
   int32_t task_body[2][GMR_MAX_TASKS];    /* robot body index of the task frame                    */
   int32_t task_human[2][GMR_MAX_TASKS];   /* index into the packed human list                      */
   int32_t task_col0[2][GMR_MAX_TASKS];    /* first pair of the task                                */
-  int32_t task_ncol[2][GMR_MAX_TASKS];    /* number of dofs on the path root -> task body (+6)     */
+  int32_t task_ncol[2][GMR_MAX_TASKS];    /* dofs listed for the task: base (6, or 3 without a position cost) + hinges root -> body */
   int32_t pair_task[2][GMR_MAX_PAIRS];
   int32_t pair_dof[2][GMR_MAX_PAIRS];     /* ascending within a task                               */
   int32_t pair_index[2][GMR_MAX_TASKS][GMR_MAX_DOF]; /* pair id of (task, dof) or -1            */
