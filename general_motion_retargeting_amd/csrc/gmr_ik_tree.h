@@ -299,10 +299,20 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
         else if (x > hi + ptol_hi) newst = 2;
       } else {
         double g0 = ci, g1 = 0.0;
+        // (eight products per trip with all their loads in flight: the stream that sets the batch's time sits on joint
+        //  limits in nearly every frame, so this row product is on the headline's critical path)
+        double g2 = 0.0, g3 = 0.0;
         int j = 0;
-        for (; j + 1 < n; j += 2) { g0 = fma(Hrow[j], xs[j], g0); g1 = fma(Hrow[j + 1], xs[j + 1], g1); }
-        if (j < n) g0 = fma(Hrow[j], xs[j], g0);
-        const double g = g0 + g1;
+        for (; j + 7 < n; j += 8) {
+          const double h0 = Hrow[j], h1 = Hrow[j + 1], h2 = Hrow[j + 2], h3 = Hrow[j + 3], h4 = Hrow[j + 4], h5 = Hrow[j + 5],
+                       h6 = Hrow[j + 6], h7 = Hrow[j + 7];
+          const double x0 = xs[j], x1 = xs[j + 1], x2 = xs[j + 2], x3 = xs[j + 3], x4 = xs[j + 4], x5 = xs[j + 5],
+                       x6 = xs[j + 6], x7 = xs[j + 7];
+          g0 = fma(h0, x0, g0); g1 = fma(h1, x1, g1); g2 = fma(h2, x2, g2); g3 = fma(h3, x3, g3);
+          g0 = fma(h4, x4, g0); g1 = fma(h5, x5, g1); g2 = fma(h6, x6, g2); g3 = fma(h7, x7, g3);
+        }
+        for (; j < n; j++) g0 = fma(Hrow[j], xs[j], g0);
+        const double g = (g0 + g1) + (g2 + g3);
         const bool at_lower = (bs.lower >> dof) & 1ull;
         if (at_lower ? g < -dual_tol : g > dual_tol) newst = 3;
       }
