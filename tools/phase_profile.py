@@ -62,6 +62,13 @@ def main():
         rt.min(), np.median(rt), rt.max(), (pr[:, 14] / pr[:, 15]).min(), (pr[:, 14] / pr[:, 15]).max()))
     for i, n in enumerate(PH[:14]):
         print(f"  {n:7s} {pr[:, i].mean() / tot * 100:6.2f} %   {pr[:, i].mean() / nsolve:10.0f} /solve")
+    if S <= 512:     # latency shape: the batch's time is its slowest stream's -- the same breakdown for that stream alone
+        k = int(np.argmax(pr[:, 17]))
+        med = int(np.argsort(pr[:, 17])[S // 2])
+        for name, i in (("slowest", k), ("median", med)):
+            ns_i, tot_i = pr[i, 15], pr[i, :14].sum()
+            print(f"  {name} stream {i}: wall {pr[i, 17] / 100.0:.0f} us, {ns_i:.0f} solves, {tot_i / ns_i:.0f} stamped cycles/solve: " +
+                  " ".join(f"{n}={pr[i, j] / ns_i:.0f}" for j, n in enumerate(PH[:14])))
     if hp.sum() > 0:
         print("  helper wavefront 1 (cycles/solve): idle at B1 %.0f, Jacobian share %.0f, wait B2 %.0f, H share %.0f, wait B3 %.0f, tree-QP %.0f" % (
             hp[:, 0].mean() / nsolve, hp[:, 4].mean() / nsolve, hp[:, 5].mean() / nsolve, hp[:, 6].mean() / nsolve,
