@@ -127,7 +127,8 @@ def main():
     strong_seed = args.seed + 1_000_003
     lens = np.full(SS, ST, dtype=np.int64)
     my_ids = sharding.lpt_partition(lens, world)[rank] if strong else []
-    workers = min(16, len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else 4
+    # generator processes of this rank: its share of the host's cores (every rank of the node generates at the same time)
+    workers = max(1, min(16, len(os.sched_getaffinity(0)) // max(1, world))) if hasattr(os, "sched_getaffinity") else 4
     if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
         workers = 1         # a profiler's preloaded tool library owns the GPU already: do not fork worker processes under it
     if strong:
