@@ -316,7 +316,8 @@ __device__ __forceinline__ void jbody_phase(const LT& L, double* sm, int stage, 
 
 // (b2) all wavefronts, after Jl^-1: Jw[p] = W_k (-Jl^-1(e_k)) Jb[p] in place, and the column's share of c
 template <class LT>
-__device__ __forceinline__ void pairs_from_jbody(const LT& L, double* sm, int stage, const StageTabs& tb, int vlane, int nvl) {
+__device__ __forceinline__ void pairs_from_jbody(const LT& L, double* sm, int stage, const StageTabs& tb, int vlane, int nvl,
+                                                 const uint32_t* zero_off) {
   const int P = L.P[stage];
   const double* wpos = sm + L.o.wpos[stage];
   const double* wrot = sm + L.o.wrot[stage];
@@ -344,6 +345,8 @@ __device__ __forceinline__ void pairs_from_jbody(const LT& L, double* sm, int st
   }
   if (vlane < 6) Jw[6 * L.o.cap.p + vlane] = 0.0;   // the row that schedule items without a term read
   if (vlane == 6) cpart[L.o.cap.p] = 0.0;           // and the c share absent (task, dof) pairs gather
+  if (vlane >= 64 && vlane - 64 < L.nzero[stage])   // the H cells that half entries are added to (a helper lane each)
+    *reinterpret_cast<double*>(reinterpret_cast<char*>(sm + L.o.H) + zero_off[vlane - 64]) = 0.0;
 }
 
 // (c) lane = dof: gather c; bounds of the limited hinges (mink ConfigurationLimit)
@@ -392,6 +395,14 @@ __device__ __forceinline__ void item_store(char* Hb, uint32_t hi, double acc, do
   *reinterpret_cast<double*>(Hb + ((hi >> 15) & 0x7fffu)) = v;
 }
 
+// a half entry's sum is ADDED to its (zeroed) cells: two addends per cell, so the order does not matter
+__device__ __forceinline__ void item_add(char* Hb, uint32_t hi, double acc, double diag) {
+  const double v = acc + ((hi & (1u << 30)) ? diag : 0.0);
+  const uint32_t o1 = hi & 0x7fffu, o2 = (hi >> 15) & 0x7fffu;
+  atomicAdd(reinterpret_cast<double*>(Hb + o1), v);
+  if (o2 != o1) atomicAdd(reinterpret_cast<double*>(Hb + o2), v);
+}
+
 template <class LT>
 __device__ __forceinline__ void hacc_phase(const LT& L, double* sm, int stage, const StageTabs& tb, double diag,
                                            int vlane) {
@@ -421,7 +432,9 @@ __device__ __forceinline__ void hacc_phase(const LT& L, double* sm, int stage, c
       if (paired) {   // wave-uniform: lanes 2i / 2i+1 hold the two halves of one entry, closed in the same slot
         if (__any((int)(w[k].y >> 31))) {
           double tot = acc + dpp_swap_pairs(acc);           // own + neighbour (commutative: the same bits in both lanes)
-          if ((w[k].y >> 31) && !(vlane & 1)) item_store(Hb, w[k].y, tot, diag);
+          if ((w[k].y >> 31) && !(vlane & 1)) {
+            if (vlane < L.atomic_lanes[stage]) item_add(Hb, w[k].y, tot, diag); else item_store(Hb, w[k].y, tot, diag);
+          }
           if (w[k].y >> 31) acc = 0.0;
         }
       } else if (w[k].y >> 31) {
@@ -494,7 +507,7 @@ __device__ __forceinline__ void build_qp_main(const LT& L, double* sm, int stage
     if (lane == 0) { int* c = ctl + 2 * (epoch & 1); c[0] = CMD_BUILD; c[1] = stage; (sm + L.o.scal)[0] = diag; }
     epoch++;
     __syncthreads();                      // B1: helpers see the command; M / we and the body Jacobians are final
-    pairs_from_jbody(L, sm, stage, tb, lane, 64 * NW);
+    pairs_from_jbody(L, sm, stage, tb, lane, 64 * NW, nullptr);      // (the main wavefront's lanes zero nothing)
     __syncthreads();                      // B2: all Jacobian columns written
     PROF_END(pr, PH_PAIRS);
     PROF_BEGIN(pr);
@@ -530,7 +543,7 @@ __device__ __forceinline__ void helper_loop(const LT& L, double* sm, const uint3
     }
     const double diag = (sm + L.o.scal)[0];
     PROF_BEGIN(hp);
-    pairs_from_jbody(L, sm, stage, tb, wave * 64 + lane, 64 * NW);
+    pairs_from_jbody(L, sm, stage, tb, wave * 64 + lane, 64 * NW, sw + L.o.w_zero + stage * IK_MAX_ZERO);
     PROF_END(hp, PH_PAIRS);
     PROF_BEGIN(hp);
     __syncthreads();                      // B2

@@ -11,6 +11,7 @@
 
 namespace gmr {
 
+constexpr int IK_MAX_ZERO = 64;  // H cells of entries whose halves are added (gmr_ik_layout.h: make_ik_schedule)
 constexpr int IK_MAX_HOPS = 5;  // pointer-jumping rounds of the FK: 2^5 = 32 > GMR_MAX_DEPTH
 
 // rows of the dense register-resident factorisation are padded to one of these sizes = the SIZE CLASS of a
@@ -42,7 +43,7 @@ struct IkOffsets {
   int i_task_body[2], i_task_human[2], i_pair_task[2], i_pair_dof[2], i_pair_index[2];
   int n_short;                   // padded to a multiple of 8 (the words start 16-byte aligned)
   // offsets in 32-bit words (after the shorts); the H-assembly schedule (runtime size) comes last
-  int w_ctl, w_tr_mask, w_tr_cnt, w_items0;
+  int w_ctl, w_tr_mask, w_tr_cnt, w_zero, w_items0;
   int fixed_bytes;               // bytes up to the schedule
 };
 
@@ -104,6 +105,7 @@ constexpr IkOffsets ik_offsets(int nvp, int nw) {
   L.w_ctl = w; w += 4;                             // two mailbox slots {command, stage}, alternating per command
   L.w_tr_mask = w; w += 16;
   L.w_tr_cnt = w; w += 4;
+  L.w_zero = w; w += 2 * IK_MAX_ZERO;              // [stage][IK_MAX_ZERO] byte offsets of the H cells zeroed per solve
   if (w % 4) w += 4 - w % 4;                       // the schedule starts 16-byte aligned
   L.w_items0 = w;
   L.fixed_bytes = L.n_double * 8 + L.n_short * 2 + w * 4;
@@ -115,6 +117,7 @@ struct IkDims {
   int nb, nh, nq, nv, nhum, nhop, tree_ok;
   int tree_small;                // limbs <= 7 dofs and trunk <= 9: the <7, 9> instance of the tree solver applies
   int K[2], P[2], ntrip[2], nlanes, pair_lanes;
+  int atomic_lanes[2], nzero[2];   // half entries added to H (helpers' schedule) and the H cells zeroed for them
   int w_items[2];                // NW > 1: word offset of a stage's schedule from the start of the words
   int g_items[2];                // NW == 1: the schedule stays in the global image at these word offsets; else -1
   int smem_bytes;
@@ -175,7 +178,9 @@ struct IkSchedule {
   // what the kernel reads: every lane padded to ntrip slots with no-op words, stored [slot][lane] so that
   // a wave reads consecutive words (conflict-free) and the loop trip count is wave-uniform
   int ntrip[2];
-  int npaired[2];                  // entries split over a lane pair
+  int npaired[2];                  // entries (or half entries) split over a lane pair
+  int atomic_lanes[2];             // the first atomic_lanes lanes close by adding to H (half entries): their cells are zeroed first
+  std::vector<int> zero_off[2];    // byte offsets in H of those cells
   std::vector<uint64_t> padded[2];
 };
 
@@ -199,49 +204,77 @@ inline IkSchedule make_ik_schedule(const gmr_model_t& m, const gmr_taskset_t& ts
           terms[(size_t)da * nv + db].push_back(48u * (uint32_t)(c0 + a) | ((48u * (uint32_t)(c0 + b)) << 16));
         }
     }
-    struct Ent { int da, db, w; };
+    // an entry, or -- for the heaviest entries of the helpers' schedule -- one HALF of its terms [t0, t1): the two halves
+    // are summed by two lane pairs and ADDED to H (LDS atomic add onto a zeroed cell; two addends commute exactly, so the
+    // result does not depend on which pair comes first).  An entry of 14 terms then costs 4 slots instead of 7.
+    struct Ent { int da, db, w, t0, t1, atomic; };
     auto dest = [&](const Ent& e) {
       return (uint64_t)((uint32_t)(8 * (e.da * ldh + e.db)) | ((uint32_t)(8 * (e.db * ldh + e.da)) << 15) |
-                        (e.da == e.db ? 1u << 30 : 0u)) << 32;
+                        (e.da == e.db && e.t0 == 0 ? 1u << 30 : 0u)) << 32;   // (the damping term rides on the first half)
     };
     std::vector<Ent> ents;
     for (int da = 0; da < nv; da++)
       for (int db = 0; db <= da; db++) {
         int w = (int)terms[(size_t)da * nv + db].size();
-        if (w > 0 || da == db) ents.push_back({da, db, w});
+        if (w > 0 || da == db) ents.push_back({da, db, w, 0, w, 0});
       }
     std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.w > y.w; });
     std::vector<std::vector<Ent>> per_lane(nlanes);
-    std::vector<int> load(nlanes, 0);
-    size_t first_single = 0;
+    std::vector<Ent> pair_ents;                   // one per lane pair of the first wavefront
+    std::vector<Ent> singles;
+    sch.atomic_lanes[s] = 0;
+    sch.zero_off[s].clear();
     if (sch.pair_lanes) {
-      // ents is sorted by weight: the heaviest pair_lanes/2 entries go to the lane pairs (marked da|64)
-      for (; first_single < ents.size() && (int)first_single < sch.pair_lanes / 2; first_single++) {
-        const Ent& e = ents[first_single];
-        if (e.w < 4) break;
-        per_lane[2 * first_single].push_back(e);
-        load[2 * first_single] = load[2 * first_single + 1] = 1 << 20;   // pair lanes take nothing else
+      const int npair = sch.pair_lanes / 2;
+      size_t nheavy = 0;
+      while (nheavy < ents.size() && ents[nheavy].w > 8) nheavy++;
+      size_t next = 0;
+      if (nheavy > 0 && 2 * (int)nheavy <= npair && 2 * (int)nheavy <= IK_MAX_ZERO) {   // split every heavy entry into two atomic halves
+        for (; next < nheavy; next++) {
+          const Ent& e = ents[next];
+          const int h = (e.w + 1) / 2;
+          pair_ents.push_back({e.da, e.db, h, 0, h, 1});
+          pair_ents.push_back({e.da, e.db, e.w - h, h, e.w, 1});
+          sch.zero_off[s].push_back(8 * (e.da * ldh + e.db));
+          if (e.da != e.db) sch.zero_off[s].push_back(8 * (e.db * ldh + e.da));
+        }
+        sch.atomic_lanes[s] = 2 * (int)pair_ents.size();
       }
-      for (int l = 2 * (int)first_single; l < sch.pair_lanes; l++) load[l] = 1 << 20;   // unused: the wavefront runs in pair mode
+      for (; next < ents.size() && (int)pair_ents.size() < npair && ents[next].w >= 4; next++) pair_ents.push_back(ents[next]);
+      for (; next < ents.size(); next++) singles.push_back(ents[next]);
+    } else {
+      singles = ents;
     }
-    for (size_t ei = first_single; ei < ents.size(); ei++) {
-      const Ent& e = ents[ei];
-      int best = -1;
-      for (int l = 0; l < nlanes; l++) if (load[l] < (1 << 20) && (best < 0 || load[l] < load[best])) best = l;
-      per_lane[best].push_back(e);
-      load[best] += std::max(e.w, 1) + 1;  // +1: the two stores of the entry
+    // single lanes: first-fit-decreasing into the smallest multiple of four slots that holds everything
+    {
+      const int l0 = sch.pair_lanes, nl1 = nlanes - l0;
+      int total = 0;
+      for (const Ent& e : singles) total += std::max(e.w, 1);
+      for (int cap = std::max(4, ((total + nl1 - 1) / nl1 + 3) & ~3);; cap += 4) {
+        for (int l = l0; l < nlanes; l++) per_lane[l].clear();
+        std::vector<int> load(nlanes, 0);
+        bool fits = true;
+        for (const Ent& e : singles) {
+          int lane = -1;
+          for (int l = l0; l < nlanes && lane < 0; l++) if (load[l] + std::max(e.w, 1) <= cap) lane = l;
+          if (lane < 0) { fits = false; break; }
+          per_lane[lane].push_back(e);
+          load[lane] += std::max(e.w, 1);
+        }
+        if (fits) break;
+      }
     }
-    sch.npaired[s] = (int)first_single;
+    sch.npaired[s] = (int)pair_ents.size();
     sch.items[s].clear();
     sch.istart[s].assign(nlanes + 1, 0);
     for (int l = 0; l < nlanes; l++) {
       sch.istart[s][l] = (int)sch.items[s].size();
       const bool paired = l < 2 * sch.npaired[s];
       if (paired) {
-        const Ent& e = per_lane[l & ~1][0];
+        const Ent& e = pair_ents[l >> 1];
         const auto& tt = terms[(size_t)e.da * nv + e.db];
-        const size_t half = (tt.size() + 1) / 2;              // both lanes get `half` slots
-        const size_t lo2 = (l & 1) ? half : 0, hi2 = (l & 1) ? tt.size() : half;
+        const size_t cnt = (size_t)(e.t1 - e.t0), half = (cnt + 1) / 2;   // both lanes get `half` slots
+        const size_t lo2 = e.t0 + ((l & 1) ? half : 0), hi2 = (l & 1) ? (size_t)e.t1 : e.t0 + half;
         const uint64_t dd = dest(e);
         for (size_t i = 0; i < half; i++) {
           const bool have = lo2 + i < hi2;
@@ -362,6 +395,10 @@ inline IkLayout make_ik_layout(const gmr_model_t& m, const gmr_taskset_t& ts, co
   for (int s = 0; s < 2; s++) { L.K[s] = ts.ntask[s]; L.P[s] = ts.npair[s]; L.nitem[s] = (int)sch.padded[s].size(); L.ntrip[s] = sch.ntrip[s]; }
   L.nlanes = sch.nlanes;
   L.pair_lanes = sch.pair_lanes;
+  for (int s = 0; s < 2; s++) {
+    L.atomic_lanes[s] = sch.atomic_lanes[s];
+    L.nzero[s] = (int)sch.zero_off[s].size();      // (<= IK_MAX_ZERO: at most 16 split entries, two cells each)
+  }
   L.o = ik_offsets(L.nvp > 0 ? L.nvp : 48, nw);
   // the schedule: in LDS after the fixed part (NW > 1), or only in the global image (NW == 1)
   int w = L.o.w_items0;
@@ -435,6 +472,8 @@ inline std::vector<char> make_ik_image(const gmr_model_t& m, const gmr_taskset_t
     const IkTree tree = make_ik_tree(m);
     for (int l = 0; l < 4; l++) for (int a2 = 0; a2 < 8; a2++) si[L.o.i_tree_limb + l * 8 + a2] = (short)tree.limb[l][a2];
     for (int t2 = 0; t2 < 10; t2++) si[L.o.i_tree_trunk + t2] = (short)tree.trunk[t2];
+    for (int s = 0; s < 2; s++)
+      for (size_t i = 0; i < sch.zero_off[s].size() && i < (size_t)IK_MAX_ZERO; i++) sw[L.o.w_zero + s * IK_MAX_ZERO + i] = (uint32_t)sch.zero_off[s][i];
     reinterpret_cast<int*>(sw + L.o.w_tr_cnt)[1] = -1;
     reinterpret_cast<int*>(sw + L.o.w_tr_cnt)[3] = -1;
   }

@@ -41,6 +41,7 @@ int main(int argc, char** argv) {
       for (int d = 0; d < nv; d++) want[{d, d}];   // diagonal always present
       std::map<std::pair<int, int>, std::multiset<std::pair<int, int>>> got;
       std::set<std::pair<int, int>> closed;
+      std::map<std::pair<int, int>, int> halves;
       CHECK((int)sch.istart[s].size() == nl + 1, "istart size");
       CHECK(sch.istart[s][0] == 0 && sch.istart[s][nl] == (int)sch.items[s].size(), "istart ends");
       int maxload = 0;
@@ -58,7 +59,9 @@ int main(int argc, char** argv) {
           std::pair<int, int> e = {o1 / ldh, o1 % ldh};
           CHECK(o2 == e.second * ldh + e.first, "the second store is the transposed entry");
           CHECK(e.first >= e.second && e.first < nv, "entry range");
-          CHECK(((hi >> 30) & 1u) == (e.first == e.second ? 1u : 0u), "diagonal flag");
+          const bool atomic_lane = l < sch.atomic_lanes[s];      // half entries, added to H by two lane pairs
+          if (!atomic_lane) CHECK(((hi >> 30) & 1u) == (e.first == e.second ? 1u : 0u), "diagonal flag");
+          else if ((hi >> 30) & 1u) { CHECK(e.first == e.second, "diagonal flag on an off-diagonal half"); }
           CHECK((lo & 0xffffu) % 48 == 0 && (lo >> 16) % 48 == 0, "row offsets must be multiples of 48");
           const int ra = (int)(lo & 0xffffu) / 48, rb = (int)(lo >> 16) / 48;
           const bool nop = ra == zero_row;
@@ -66,8 +69,13 @@ int main(int argc, char** argv) {
           const uint32_t w = (nop ? 1u << 30 : 0u) | (hi & (1u << 31)) | (uint32_t)ra | ((uint32_t)rb << 9);
           const bool pairlane = l < 2 * sch.npaired[s];
           if (open) CHECK(e == cur, "terms of one entry must be contiguous in one lane");
-          else { CHECK(pairlane ? (!(l & 1) ? !closed.count(e) : closed.count(e) == 1) : !closed.count(e),
-                       "entry (%d,%d) owned twice", e.first, e.second); cur = e; open = true; }
+          else {
+            if (!atomic_lane)
+              CHECK(pairlane ? (!(l & 1) ? !closed.count(e) : closed.count(e) == 1) : !closed.count(e),
+                    "entry (%d,%d) owned twice", e.first, e.second);
+            else halves[e]++;                                     // counted below: four lanes (two pairs) per split entry
+            cur = e; open = true;
+          }
           if (!((w >> 30) & 1u)) got[e].insert({(int)(w & 511u), (int)((w >> 9) & 511u)});
           else got[e];
           if (w >> 31) { closed.insert(e); open = false; }
@@ -76,10 +84,22 @@ int main(int argc, char** argv) {
       }
       for (int i = 0; i < sch.npaired[s]; i++)   // the two halves of a pair close in the same slot
         CHECK(sch.istart[s][2 * i + 1] - sch.istart[s][2 * i] == sch.istart[s][2 * i + 2] - sch.istart[s][2 * i + 1], "pair %d halves differ in length", i);
+      CHECK(sch.atomic_lanes[s] % 4 == 0 && sch.atomic_lanes[s] <= sch.pair_lanes, "atomic lanes");
+      {
+        std::set<int> zero(sch.zero_off[s].begin(), sch.zero_off[s].end());
+        CHECK(zero.size() == sch.zero_off[s].size() && (int)zero.size() <= gmr::IK_MAX_ZERO, "zero list");
+        for (auto& h : halves) {
+          CHECK(h.second == 4, "split entry (%d,%d) seen on %d lanes", h.first.first, h.first.second, h.second);
+          CHECK(zero.count(8 * (h.first.first * ldh + h.first.second)) && zero.count(8 * (h.first.second * ldh + h.first.first)),
+                "cells of a split entry must be zeroed");
+        }
+        CHECK((int)halves.size() * 4 == sch.atomic_lanes[s], "atomic lanes = four per split entry");
+      }
       CHECK(got == want, "stage %d: schedule terms differ from J^T J structure (%zu vs %zu entries)", s, got.size(), want.size());
       CHECK(closed.size() == want.size(), "unclosed entries");
       int total = (int)sch.items[s].size();
-      CHECK(maxload <= (total + nl - 1) / nl + ts.ntask[s] + 2, "schedule badly balanced: max %d of %d over %d lanes", maxload, total, nl);
+      // (lanes are filled up to the four slots of one loop trip)
+      CHECK(maxload <= std::max(4, (total + nl - 1) / nl + ts.ntask[s] + 2), "schedule badly balanced: max %d of %d over %d lanes", maxload, total, nl);
     }
   }
   // tree decomposition
