@@ -24,14 +24,14 @@ __device__ __forceinline__ d4 qmul(d4 a, d4 b) {
           a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
 }
 // 1/sqrt(x) for a normal-range positive x (pivots of an SPD matrix, squared quaternion norms):
-// v_rsq_f64 seed + two Newton steps, no range scaling / special-case handling -> ~1 ulp, a third of
-// the dependent latency of the library rsqrt.  NaN / non-positive inputs stay NaN (callers test).
+// v_rsq_f64 seed (24 bits) + ONE third-order step y (1 + e/2 + 3 e^2 / 8), e = 1 - x y^2: 1.7e-16 relative error measured
+// over 2^20 inputs (two Newton steps: 2.4e-16; tools/micro/rsq_check.hip) with four instead of six dependent
+// operations -- the pivots of the factorisations wait on this chain.  No range scaling / special cases: NaN and
+// non-positive inputs stay NaN (callers test).
 __device__ __forceinline__ double fast_rsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  const double h = 0.5 * x;
-  y = y * fma(-h * y, y, 1.5);
-  y = y * fma(-h * y, y, 1.5);
-  return y;
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x, y * y, 1.0);
+  return fma(y * e, fma(0.375, e, 0.5), y);
 }
 
 __device__ __forceinline__ d4 qconj(d4 a) { return {a.w, -a.x, -a.y, -a.z}; }
