@@ -282,8 +282,14 @@ __device__ __forceinline__ void hacc_wide(double* sm, const char* __restrict__ i
     for (int k = 0; k < 4; k++) {
       acc += s[k];
       if ((int)w[k].y < 0) {
-        *reinterpret_cast<double*>(Hb + (w[k].y & 0x1fffu)) = acc;
-        *reinterpret_cast<double*>(Hb + ((w[k].y >> 13) & 0x1fffu)) = acc;
+        const uint32_t o1 = w[k].y & 0x1fffu, o2 = (w[k].y >> 13) & 0x1fffu;
+        if (w[k].y & WD_ITEM_ADD) {     // half of a heavy entry: the cell was zeroed above, the two halves commute
+          atomicAdd(reinterpret_cast<double*>(Hb + o1), acc);
+          if (o2 != o1) atomicAdd(reinterpret_cast<double*>(Hb + o2), acc);
+        } else {
+          *reinterpret_cast<double*>(Hb + o1) = acc;
+          *reinterpret_cast<double*>(Hb + o2) = acc;
+        }
         acc = 0.0;
       }
     }

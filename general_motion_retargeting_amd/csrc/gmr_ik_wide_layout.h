@@ -151,6 +151,7 @@ struct WideLayout : WideDims {
 // beside its six FMAs.  lo: [15:0] byte offset of Jw row a, [31:16] of row b (padding items name the zero row WD_P
 // twice).  hi: [12:0] first store offset in the compact H (bytes), [25:13] second store offset (the symmetric twin, or
 // the same), [31] last term of the entry.  The damping term of the diagonal is added by the dof lanes afterwards.
+constexpr uint32_t WD_ITEM_ADD = 1u << 30;   // (in the high word, with the close flag) this lane holds half of the entry: add, do not store
 constexpr uint32_t WD_ITEM_NOP = (48u * WD_P) | ((48u * WD_P) << 16);
 static_assert(48 * WD_P < 65536 && 8 * WD_HN < 8192, "item fields");
 
@@ -168,6 +169,20 @@ inline bool wide_fits(const gmr_model_t& m, const gmr_taskset_t& ts) {
   return maxd <= 32;
 }
 
+// Where pair p of the task set lives in the kernel's tables (Jw row, c share, virtual lane of the pairs phase): base
+// rotation columns first, then base translations, then hinges.  The pairs phase branches on that class; with the
+// classes contiguous a 64-lane trip runs one or two of the three branches instead of all of them.  Sums are taken in
+// task order whatever the slots are, so the order does not touch the arithmetic.
+inline std::vector<int> wide_pair_slots(const gmr_taskset_t& ts, int s) {
+  const int P = ts.npair[s];
+  std::vector<int> order(P), slot(P);
+  for (int p = 0; p < P; p++) order[p] = p;
+  auto cls = [&](int p) { const int d = ts.pair_dof[s][p]; return d < 3 ? 1 : (d < 6 ? 0 : 2); };
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cls(x) < cls(y); });
+  for (int i = 0; i < P; i++) slot[order[i]] = i;
+  return slot;
+}
+
 // Static schedule of H = sum_k (W J_k)^T (W J_k) (see gmr_ik_layout.h) with the destinations expressed in the
 // compact layout: every (i >= j) entry is owned by one lane (longest-processing-time assignment) which sums its
 // terms in a fixed order and stores the entry once (twice for a symmetric twin).
@@ -179,16 +194,17 @@ inline bool make_wide_schedule(const gmr_model_t& m, const gmr_taskset_t& ts, st
   for (int t = 0; t < 10; t++) if (tree.trunk[t] >= 0) loc[tree.trunk[t]] = {-1, t};
   for (int s = 0; s < 2; s++) {
     std::vector<std::vector<uint32_t>> terms((size_t)nv * nv);
+    const std::vector<int> slot = wide_pair_slots(ts, s);
     for (int k = 0; k < ts.ntask[s]; k++) {
       int c0 = ts.task_col0[s][k], n = ts.task_ncol[s][k];
       for (int a = 0; a < n; a++)
         for (int b = 0; b <= a; b++) {
           int da = ts.pair_dof[s][c0 + a], db = ts.pair_dof[s][c0 + b];
-          terms[(size_t)da * nv + db].push_back(48u * (uint32_t)(c0 + a) | ((48u * (uint32_t)(c0 + b)) << 16));
+          terms[(size_t)da * nv + db].push_back(48u * (uint32_t)slot[c0 + a] | ((48u * (uint32_t)slot[c0 + b]) << 16));
         }
     }
-    struct Ent { int da, db, w; uint32_t hi; };
-    std::vector<Ent> ents;
+    struct Ent { int da, db, w, first; uint32_t hi; };           // terms [first, first + w) of entry (da, db)
+    std::vector<Ent> whole;
     for (int da = 0; da < nv; da++)
       for (int db = 0; db <= da; db++) {
         int w = (int)terms[(size_t)da * nv + db].size();
@@ -201,35 +217,52 @@ inline bool make_wide_schedule(const gmr_model_t& m, const gmr_taskset_t& ts, st
         } else if (A.limb >= 0) { o1 = o2 = (16 * A.limb + 7 + B.idx) * 7 + A.idx; }
         else if (B.limb >= 0) { o1 = o2 = (16 * B.limb + 7 + A.idx) * 7 + B.idx; }
         else { o1 = WD_HT + A.idx * WD_NT + B.idx; o2 = WD_HT + B.idx * WD_NT + A.idx; }
-        ents.push_back({da, db, w, (uint32_t)(8 * o1) | ((uint32_t)(8 * o2) << 13)});
+        whole.push_back({da, db, w, 0, (uint32_t)(8 * o1) | ((uint32_t)(8 * o2) << 13)});
       }
-    std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.w > y.w; });
     // A lane's cost is its number of terms (an entry's two stores ride on its last term).  The loop runs four slots per
     // trip, so what counts is the smallest multiple of four every lane fits in: first-fit-decreasing bin packing into 64
     // lanes of that capacity, the capacity raised until it works (G1: 1 014 terms -> 16 slots, the minimum).
-    std::vector<std::vector<Ent>> per_lane;
-    int total = 0;
-    for (const Ent& e : ents) total += e.w;
-    for (int cap = std::max(4, ((total + 63) / 64 + 3) & ~3);; cap += 4) {
-      per_lane.assign(64, {});
-      std::vector<int> load(64, 0);
-      bool fits = true;
-      for (const Ent& e : ents) {
-        int lane = -1;
-        for (int l = 0; l < 64 && lane < 0; l++) if (load[l] + e.w <= cap) lane = l;
-        if (lane < 0) { fits = false; break; }
-        per_lane[lane].push_back(e);
-        load[lane] += e.w;
+    // An entry heavier than the mean load would alone set that capacity (G1's pruned first table: 666 terms, 10.4 per
+    // lane, but 14 in each base-rotation entry): such entries are cut into two halves owned by two lanes, each ADDING
+    // its sum to the zero-filled cell (WD_ITEM_ADD; two addends commute exactly) -- kept only when it saves a trip.
+    auto pack = [&](const std::vector<Ent>& ents_in, std::vector<std::vector<Ent>>& per_lane) {
+      std::vector<Ent> ents = ents_in;
+      std::stable_sort(ents.begin(), ents.end(), [](const Ent& x, const Ent& y) { return x.w > y.w; });
+      int total = 0;
+      for (const Ent& e : ents) total += e.w;
+      for (int cap = std::max(4, ((total + 63) / 64 + 3) & ~3);; cap += 4) {
+        per_lane.assign(64, {});
+        std::vector<int> load(64, 0);
+        bool fits = true;
+        for (const Ent& e : ents) {
+          int lane = -1;
+          for (int l = 0; l < 64 && lane < 0; l++) if (load[l] + e.w <= cap) lane = l;
+          if (lane < 0) { fits = false; break; }
+          per_lane[lane].push_back(e);
+          load[lane] += e.w;
+        }
+        if (fits) return cap;
       }
-      if (fits) break;
+    };
+    std::vector<std::vector<Ent>> per_lane, per_lane_cut;
+    const int cap_whole = pack(whole, per_lane);
+    {
+      std::vector<Ent> cut;
+      for (const Ent& e : whole) {
+        if (e.w <= 8) { cut.push_back(e); continue; }
+        const int h = (e.w + 1) / 2;
+        cut.push_back({e.da, e.db, h, 0, e.hi | WD_ITEM_ADD});
+        cut.push_back({e.da, e.db, e.w - h, h, e.hi | WD_ITEM_ADD});
+      }
+      if (pack(cut, per_lane_cut) < cap_whole) per_lane.swap(per_lane_cut);
     }
     int nt = 0;
     std::vector<std::vector<uint64_t>> li(64);
     for (int l = 0; l < 64; l++) {
       for (const Ent& e : per_lane[l]) {
         const auto& tt = terms[(size_t)e.da * nv + e.db];
-        for (size_t i = 0; i < tt.size(); i++)
-          li[l].push_back(((uint64_t)(e.hi | (i + 1 == tt.size() ? (1u << 31) : 0u)) << 32) | tt[i]);
+        for (int i = e.first; i < e.first + e.w; i++)
+          li[l].push_back(((uint64_t)(i + 1 == e.first + e.w ? (e.hi | (1u << 31)) : (e.hi & ~WD_ITEM_ADD)) << 32) | tt[i]);
       }
       nt = std::max(nt, (int)li[l].size());
     }
@@ -288,16 +321,17 @@ inline WideLayout make_wide_layout(const gmr_model_t& m, const gmr_taskset_t& ts
       F(I.task[s])[2 * k + 1] = ts.w_rot[s][k];
       U(I.taski[s])[k] = (uint32_t)ts.task_body[s][k] | ((uint32_t)ts.task_human[s][k] << 8);
     }
+    const std::vector<int> slot = wide_pair_slots(ts, s);
     for (int p = 0; p < ts.npair[s]; p++) {
       const int k = ts.pair_task[s][p], d = ts.pair_dof[s][p];
-      U(I.pair[s])[p] = (uint32_t)k | ((uint32_t)d << 4) | ((uint32_t)ts.task_body[s][k] << 10) |
+      U(I.pair[s])[slot[p]] = (uint32_t)k | ((uint32_t)d << 4) | ((uint32_t)ts.task_body[s][k] << 10) |
                         ((uint32_t)(d >= 6 ? m.hinge_body[d - 6] : 0) << 16);
     }
     uint16_t* ci = reinterpret_cast<uint16_t*>(base + I.cidx[s]);     // [k / 2][lane][k % 2]
     for (int k = 0; k < WD_K; k++)
       for (int d = 0; d < 64; d++) {
         int v = (k < ts.ntask[s] && d < m.nv) ? ts.pair_index[s][k][d] : -1;
-        ci[((k / 2) * 64 + d) * 2 + (k % 2)] = (uint16_t)(8 * (v >= 0 ? v : WD_P));
+        ci[((k / 2) * 64 + d) * 2 + (k % 2)] = (uint16_t)(8 * (v >= 0 ? slot[v] : WD_P));
       }
     std::memcpy(base + L.items[s], items[s].data(), items[s].size() * 8);
   }

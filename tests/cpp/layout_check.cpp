@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../general_motion_retargeting_amd/csrc/gmr_ik_layout.h"
+#include "../../general_motion_retargeting_amd/csrc/gmr_ik_wide_layout.h"
 
 #define CHECK(c, ...) do { if (!(c)) { std::fprintf(stderr, "CHECK failed: %s : ", #c); std::fprintf(stderr, __VA_ARGS__); std::fprintf(stderr, "\n"); return 1; } } while (0)
 
@@ -151,6 +152,42 @@ int main(int argc, char** argv) {
       CHECK(L.o.H + nv * L.o.ldh <= L.o.c, "H overlaps c");
     }
     lds[nw == 4] = L.smem_bytes; nd[nw == 4] = L.o.n_double; nwd[nw == 4] = (L.smem_bytes - L.o.n_double * 8 - L.o.n_short * 2) / 4;
+  }
+  // the one-wavefront-per-stream kernel's tables: pair slots are a permutation with the three dof classes contiguous, and
+  // the H schedule names exactly the expected (row, row) terms through those slots, closing every entry once
+  if (gmr::wide_fits(m, ts)) {
+    std::vector<uint64_t> items[2];
+    int ntrip[2];
+    CHECK(gmr::make_wide_schedule(m, ts, items, ntrip), "wide schedule");
+    for (int s = 0; s < 2; s++) {
+      const std::vector<int> slot = gmr::wide_pair_slots(ts, s);
+      std::set<int> seen(slot.begin(), slot.end());
+      CHECK((int)slot.size() == ts.npair[s] && (int)seen.size() == ts.npair[s] && (seen.empty() || (*seen.begin() == 0 && *seen.rbegin() == ts.npair[s] - 1)), "slots are a permutation");
+      std::vector<int> cls(ts.npair[s]);
+      for (int p = 0; p < ts.npair[s]; p++) cls[slot[p]] = ts.pair_dof[s][p] < 3 ? 1 : (ts.pair_dof[s][p] < 6 ? 0 : 2);
+      for (int i = 1; i < ts.npair[s]; i++) CHECK(cls[i - 1] <= cls[i], "dof classes contiguous");
+      std::multiset<std::pair<int, int>> want, got;
+      std::set<std::pair<int, int>> ents;
+      for (int k = 0; k < ts.ntask[s]; k++) {
+        int c0 = ts.task_col0[s][k], n = ts.task_ncol[s][k];
+        for (int a = 0; a < n; a++)
+          for (int b = 0; b <= a; b++) { want.insert({slot[c0 + a], slot[c0 + b]}); ents.insert({ts.pair_dof[s][c0 + a], ts.pair_dof[s][c0 + b]}); }
+      }
+      CHECK(ntrip[s] % 4 == 0 && (int)items[s].size() == 64 * ntrip[s], "wide trips");
+      int closes = 0, halves = 0;
+      for (uint64_t w : items[s]) {
+        const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+        if (lo == gmr::WD_ITEM_NOP) { CHECK(!(hi >> 31), "padding never stores"); continue; }
+        CHECK((lo & 0xffffu) % 48 == 0 && (lo >> 16) % 48 == 0, "row offsets");
+        got.insert({(int)(lo & 0xffffu) / 48, (int)(lo >> 16) / 48});
+        closes += hi >> 31;
+        halves += (hi >> 31) && (hi & gmr::WD_ITEM_ADD);
+        CHECK((hi >> 31) || !(hi & gmr::WD_ITEM_ADD), "the add flag rides on a closing term");
+      }
+      CHECK(got == want, "wide H terms (stage %d)", s);
+      // an entry is closed by one store, or by the two adds of its halves
+      CHECK(halves % 2 == 0 && closes - halves / 2 == (int)ents.size(), "every entry closed once: %d (%d halves) of %d", closes, halves, (int)ents.size());
+    }
   }
   // stage flags: bit 1 of use1 = both tables name the same tasks, bit 2 = and the same (task, dof) pairs
   const gmr::IkParams prm = gmr::make_ik_params(m, ts);
