@@ -92,3 +92,22 @@ def test_fk_tree_partition_for_the_split_walk(split_checker):
         assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (name, out.stdout, out.stderr)
         if name == "unitree_g1":        # four wavefronts walk at most 13 of the 38 bodies each
             assert "maxw=4 nw=4 longest=13" in out.stdout, out.stdout
+
+
+def test_layout_code_is_clean_under_sanitizers(tmp_path):
+    """The host-side schedule / layout builders (what gmr_solver_create runs before any launch) under
+    AddressSanitizer + UBSan for every shipped (source, robot) pair: a table written out of bounds on the host would
+    become an out-of-bounds LDS or global access on the GPU."""
+    exe = str(tmp_path / "layout_check_asan")
+    cc = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                         "-o", exe, SRC], capture_output=True, text=True)
+    if cc.returncode != 0:
+        pytest.skip("sanitizer runtime not available: " + cc.stderr[-200:])
+    for src, robot in ALL_CONFIGS:
+        su = get_setup(src, robot, 1.7)
+        blob = tmp_path / "blob.bin"
+        with open(blob, "wb") as f:
+            f.write(su.mb.tobytes())
+            f.write(su.ts.tobytes())
+        out = subprocess.run([exe, str(blob)], capture_output=True, text=True)
+        assert out.returncode == 0 and "runtime error" not in out.stderr and "ERROR" not in out.stderr, (src, robot, out.stderr[-2000:])
