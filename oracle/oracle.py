@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libgmr_oracle.so")
+_SO = os.environ.get("GMR_ORACLE_LIBRARY") or os.path.join(_HERE, "libgmr_oracle.so")   # (override: a sanitizer build, tests)
 _lib = None
 
 
