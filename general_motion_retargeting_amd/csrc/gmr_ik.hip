@@ -70,6 +70,13 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// value of lane `addr / 4` (per-lane index), all lanes active
+__device__ __forceinline__ double bpermute_d(int addr, double v) {
+  int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+  int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double dot6(const double* a, const double* b) {
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
 }
@@ -113,24 +120,19 @@ __device__ __forceinline__ void fk_wave(const LT& L, double* sm, const short* ho
       }
     }
   }
-  // after round r a body's transform is relative to its ancestor 2^(r+1) levels up (or the world);
-  // rounds alternate between the two buffers so that one barrier per round suffices
+  // after round r a body's transform is relative to its ancestor 2^(r+1) levels up (or the world).  The bodies are the
+  // lanes of this one wavefront, so a round takes the ancestor's transform straight out of that lane's registers
+  // (ds_bpermute: every lane is read as it was BEFORE the round, which is what pointer jumping needs): no staging
+  // buffer, no fence, no dependent index -> address -> data chain through LDS.
   for (int r = 0; r < L.nhop; r++) {
-    double* wb = sm + ((r & 1) ? L.o.xa : L.o.xb);
-    if (lane < nb) {
-      double* o = wb + 7 * lane;
-      o[0] = pos.x; o[1] = pos.y; o[2] = pos.z; o[3] = quat.w; o[4] = quat.x; o[5] = quat.y; o[6] = quat.z;
-    }
-    WSYNC();
+    const int src = 4 * hop[r * L.o.cap.nb + (lane < nb ? lane : 0)];        // byte address of the source lane
+    const d3 pa = {bpermute_d(src, pos.x), bpermute_d(src, pos.y), bpermute_d(src, pos.z)};
+    const d4 qa = {bpermute_d(src, quat.w), bpermute_d(src, quat.x), bpermute_d(src, quat.y), bpermute_d(src, quat.z)};
     if (lane < nb && dep >= (1 << r)) {
-      const double* a = wb + 7 * hop[r * L.o.cap.nb + lane];
-      d4 qa = {a[3], a[4], a[5], a[6]};
-      pos = d3{a[0], a[1], a[2]} + qrot(qa, pos);
+      pos = pa + qrot(qa, pos);
       quat = qmul(qa, quat);
     }
   }
-  // the result always goes to xa; if the last round read from xa, wait before overwriting it
-  if (L.nhop > 0 && ((L.nhop - 1) & 1)) WSYNC();
   if (lane < nb) {
     quat = qnormalize(quat);
     double* o = sm + L.o.xa + 7 * lane;
