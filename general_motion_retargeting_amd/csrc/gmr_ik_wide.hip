@@ -44,6 +44,13 @@ __device__ __forceinline__ const T* img_at(const char* img, int byte_off) {
   return reinterpret_cast<const T*>(img + byte_off);
 }
 
+// value of lane `addr / 4` (per-lane index), all lanes active
+__device__ __forceinline__ double bpermute_d(int addr, double v) {
+  int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+  int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 // ---------------------------------------------------------------------------------------------
 // FK: mj_kinematics semantics (App. A.3) by pointer jumping, lane = body (see fk_wave in gmr_ik.hip)
 // ---------------------------------------------------------------------------------------------
@@ -78,21 +85,16 @@ __device__ __forceinline__ void fk_wide(const WideDims& D, double* sm, const cha
       }
     }
   }
+  // (the ancestor's transform comes out of its lane's registers as they were before the round: no staging through LDS)
   for (int r = 0; r < D.nhop; r++) {
-    double* wb = sm + ((r & 1) ? LD.xa : LD.xb);
-    if (lane < nb) {
-      double* o = wb + 7 * lane;
-      o[0] = pos.x; o[1] = pos.y; o[2] = pos.z; o[3] = quat.w; o[4] = quat.x; o[5] = quat.y; o[6] = quat.z;
-    }
-    wsync();
+    const int src = (int)(((hops >> (6 * r)) & 63u) << 2);                    // byte address of the source lane
+    const d3 pa = {bpermute_d(src, pos.x), bpermute_d(src, pos.y), bpermute_d(src, pos.z)};
+    const d4 qa = {bpermute_d(src, quat.w), bpermute_d(src, quat.x), bpermute_d(src, quat.y), bpermute_d(src, quat.z)};
     if (lane < nb && dep >= (1 << r)) {
-      const double* a = wb + 7 * ((hops >> (6 * r)) & 63u);
-      d4 qa = {a[3], a[4], a[5], a[6]};
-      pos = d3{a[0], a[1], a[2]} + qrot(qa, pos);
+      pos = pa + qrot(qa, pos);
       quat = qmul(qa, quat);
     }
   }
-  if (D.nhop > 0 && ((D.nhop - 1) & 1)) wsync();       // the last round read from xa
   if (lane < nb) {
     quat = qnormalize(quat);
     double* o = sm + LD.xa + 7 * lane;
