@@ -527,6 +527,8 @@ __device__ __forceinline__ void helper_loop(const LT& L, double* sm, const uint3
                                             const short* hinge_body, const int* ctl, int wave, int lane,
                                             Prof& hp) {
   TreeState bs = {0ull, 0ull};            // bound sets of the QP (identical in every wavefront)
+  const TreeRows<16> rows_s = tree_rows<7, 9, false>(L, si, wave, lane);
+  const TreeRows<18> rows_l = tree_rows<8, 10, false>(L, si, wave, lane);
   for (int epoch = 0;; epoch++) {         // command n sits in mailbox slot n & 1 (see the main wavefront)
     PROF_BEGIN(hp);
     __syncthreads();                      // B1 (or the EXIT barrier)
@@ -557,8 +559,8 @@ __device__ __forceinline__ void helper_loop(const LT& L, double* sm, const uint3
     __syncthreads();                      // B3
     PROF_END(hp, PH_JLOG);                // wait at B3
     // NW > 1 is only launched for robots that decompose
-    if (QP == QP_TREE_SMALL) (void)solve_qp_tree<7, 9, false, true>(L, sm, const_cast<uint32_t*>(sw), si, wave, lane, bs, hp);
-    else (void)solve_qp_tree<8, 10, false, false>(L, sm, const_cast<uint32_t*>(sw), si, wave, lane, bs, hp);
+    if (QP == QP_TREE_SMALL) (void)solve_qp_tree<7, 9, false, true>(L, sm, const_cast<uint32_t*>(sw), si, wave, lane, bs, hp, rows_s);
+    else (void)solve_qp_tree<8, 10, false, false>(L, sm, const_cast<uint32_t*>(sw), si, wave, lane, bs, hp, rows_l);
   }
 }
 
@@ -871,6 +873,10 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
   int stat = GMR_STATUS_OK;
   int qp_state = 0;     // this lane's bound state of the previous solve (QP warm start)
   TreeState tree_state = {0ull, 0ull};
+  // (only the instance's own solver's table is live: the others are dead code per template instance)
+  const TreeRows<16> rows_s = (NW > 1 && QP == QP_TREE_SMALL) ? tree_rows<7, 9, false>(L, si, 0, lane) : TreeRows<16>{};
+  const TreeRows<18> rows_l = (NW > 1 && QP != QP_TREE_SMALL) ? tree_rows<8, 10, false>(L, si, 0, lane) : TreeRows<18>{};
+  const TreeRows<16> rows_r = (NW == 1 && QP == QP_TREE_SMALL) ? tree_rows<7, 9, true>(L, si, 0, lane) : TreeRows<16>{};
   int h_stage = -1;     // stage whose sparsity pattern H currently holds
   // Commands to the helper wavefronts go through a two-slot mailbox, alternating per command: a helper reads the slot
   // of command n right after the barrier that publishes it, the main wavefront writes command n + 1 into the OTHER
@@ -931,11 +937,11 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
           if (NW > 1) {   // the 4-wavefront shape is only launched for robots that decompose (gmr_abi.hip)
             PROF_COUNT(pr, PH_NFACT);
             // helpers joined after barrier B3
-            rc = QP == QP_TREE_SMALL ? solve_qp_tree<7, 9, false, true>(L, sm, sw, si, 0, lane, tree_state, pr)
-                                     : solve_qp_tree<8, 10, false, false>(L, sm, sw, si, 0, lane, tree_state, pr);
+            rc = QP == QP_TREE_SMALL ? solve_qp_tree<7, 9, false, true>(L, sm, sw, si, 0, lane, tree_state, pr, rows_s)
+                                     : solve_qp_tree<8, 10, false, false>(L, sm, sw, si, 0, lane, tree_state, pr, rows_l);
           } else if (QP == QP_TREE_SMALL) {   // one wavefront, the four limbs in its four 16-lane rows
             PROF_COUNT(pr, PH_NFACT);
-            rc = solve_qp_tree<7, 9, true, true>(L, sm, sw, si, 0, lane, tree_state, pr);
+            rc = solve_qp_tree<7, 9, true, true>(L, sm, sw, si, 0, lane, tree_state, pr, rows_r);
           } else {
             rc = solve_qp_regs<NVP, NW>(L, sm, lane, qp_state, pr);
           }

@@ -43,9 +43,28 @@ struct TreeState { unsigned long long lower, upper; };
 // "row", v_readlane broadcasts become DPP row broadcasts (one instruction pair serves all four limbs; the
 // result stays in a VGPR), workgroup barriers become LDS fences.  Replaces the dense 36-pivot factorisation
 // of the throughput shape for robots that fit.
+// What a wavefront reads from the decomposition tables for every solve: the dof of its row and the (wave-uniform) dofs
+// of its local matrix' columns.  They never change during a launch: read once (tree_rows), kept in registers.
+template <int TR_NV>
+struct TreeRows { int dof; int cdof[TR_NV]; };
+
+template <int TR_NL, int TR_NT, bool ROWS, class LT>
+__device__ __forceinline__ TreeRows<TR_NL + TR_NT> tree_rows(const LT& L, const short* si, int wave_in, int lane_in) {
+  const int wave = ROWS ? (lane_in >> 4) : wave_in, lane = ROWS ? (lane_in & 15) : lane_in;
+  const short* limb = si + L.o.i_tree_limb + wave * TR_MAX_NL;
+  const short* trunk = si + L.o.i_tree_trunk;
+  TreeRows<TR_NL + TR_NT> R;
+  R.dof = lane < TR_NL ? limb[lane] : (lane < TR_NL + TR_NT ? trunk[lane - TR_NL] : -1);
+#pragma unroll
+  for (int m = 0; m < TR_NL; m++) R.cdof[m] = limb[m];
+#pragma unroll
+  for (int u = 0; u < TR_NT; u++) R.cdof[TR_NL + u] = trunk[u];
+  return R;
+}
+
 template <int TR_NL, int TR_NT, bool ROWS, bool DPPB, class LT>
 __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* sw, const short* si, int wave_in,
-                                             int lane_in, TreeState& bs, Prof& pr) {
+                                             int lane_in, TreeState& bs, Prof& pr, const TreeRows<TR_NL + TR_NT>& rows) {
   constexpr int TR_NV = TR_NL + TR_NT;             // local matrix order
   static_assert(!ROWS || TR_NV <= 16, "a limb's local matrix must fit one 16-lane row");
   const int wave = ROWS ? (lane_in >> 4) : wave_in;        // which limb this wavefront / row eliminates
@@ -64,8 +83,6 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
 #define TR_SYNC() do { if (ROWS) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); else __syncthreads(); } while (0)
   const int n = L.nv, ldh = L.o.ldh;
   const double* H = sm + L.o.H;
-  const short* limb = si + L.o.i_tree_limb + wave * TR_MAX_NL;     // dof of limb row a, or -1
-  const short* trunk = si + L.o.i_tree_trunk;                  // dof of trunk row t, or -1
   double* xs = sm + L.o.x;
   const double* los = sm + L.o.lo;
   const double* his = sm + L.o.hi;
@@ -77,7 +94,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
 
   const bool is_limb = lane < TR_NL, is_trunk = lane >= TR_NL && lane < TR_NV;
   const int a = lane, t = lane - TR_NL;
-  const int dof = is_limb ? limb[a] : (is_trunk ? trunk[t] : -1);
+  const int dof = rows.dof;                                  // dof of limb row a / trunk row t, or -1
   const bool row = dof >= 0;                                 // this lane holds a real row
   const bool own = row && (is_limb || wave == 0);            // ... and reports the variable's violations
   const double lo = row ? los[dof] : 0.0, hi = row ? his[dof] : 0.0;
@@ -86,11 +103,7 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
   double dual_tol = -1.0;                                      // 1e-13 (1 + max |c|): computed when a multiplier is first checked
   const double ptol_lo = 1e-12 * (1.0 + fabs(lo)), ptol_hi = 1e-12 * (1.0 + fabs(hi));
   // column dofs of the local matrix (wave-uniform): limb columns then trunk columns
-  int cdof[TR_NV];
-#pragma unroll
-  for (int m = 0; m < TR_NL; m++) cdof[m] = limb[m];
-#pragma unroll
-  for (int u = 0; u < TR_NT; u++) cdof[TR_NL + u] = trunk[u];
+  const int* cdof = rows.cdof;
 
   int pcount = 3, ninf_best = 65;
   for (int it = 0; it < 100; it++) {
