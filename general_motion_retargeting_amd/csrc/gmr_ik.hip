@@ -89,34 +89,53 @@ namespace gmr {
 // FK: mj_kinematics semantics (App. A.3), evaluated by pointer jumping.  lane b < nb.
 // Result: (pos, quat) per body at sm[L.o.xa + 7 b], world hinge axes at sm[L.o.xaxis + 3 b].
 // ---------------------------------------------------------------------------------------------
+// A body lane's constants of the walk (parent-relative pose, hinge, source lanes of the jumping rounds): read once per
+// launch (fk_lane), kept in registers -- at every evaluation they were an index -> address -> data chain through LDS.
+struct FkLane {
+  int dep, hinge, src[IK_MAX_HOPS];
+  d4 bq; d3 bp, ax;
+};
+
+template <class LT>
+__device__ __forceinline__ FkLane fk_lane(const LT& L, const double* sm, const short* hop, const short* depth,
+                                          const short* body_hinge, int lane) {
+  FkLane F;
+  const int b = lane < L.nb ? lane : 0;
+  F.dep = lane < L.nb ? depth[b] : 0;
+  F.hinge = lane < L.nb ? body_hinge[b] : -1;
+#pragma unroll
+  for (int r = 0; r < IK_MAX_HOPS; r++) F.src[r] = r < L.nhop ? 4 * hop[r * L.o.cap.nb + b] : 0;   // byte address of the source lane
+  const double* bq = sm + L.o.body_quat + 4 * b;
+  const double* bp = sm + L.o.body_pos + 3 * b;
+  const double* ax = sm + L.o.axis + 3 * b;
+  F.bq = d4{bq[0], bq[1], bq[2], bq[3]};
+  F.bp = d3{bp[0], bp[1], bp[2]};
+  F.ax = d3{ax[0], ax[1], ax[2]};
+  return F;
+}
+
 template <int NW, class LT>
-__device__ __forceinline__ void fk_wave(const LT& L, double* sm, const short* hop, const short* depth,
-                                        const short* body_hinge, int lane, Prof& pr) {
+__device__ __forceinline__ void fk_wave(const LT& L, double* sm, const FkLane& F, int lane, Prof& pr) {
   lane = fresh_lane(lane);
   PROF_BEGIN(pr);
   const int nb = L.nb;
   double* q = sm + L.o.q;
   d3 pos = {0, 0, 0};
   d4 quat = {1, 0, 0, 0};
-  int dep = 0;
+  const int dep = F.dep;
   // round 0 input: transform of every body relative to its parent (body 0: world pose)
   if (lane < nb) {
-    dep = depth[lane];
     if (lane == 0) {
       quat = qnormalize(d4{q[3], q[4], q[5], q[6]});
       q[3] = quat.w; q[4] = quat.x; q[5] = quat.y; q[6] = quat.z;
       pos = d3{q[0], q[1], q[2]};
     } else {
-      const double* bq = sm + L.o.body_quat + 4 * lane;
-      const double* bp = sm + L.o.body_pos + 3 * lane;
-      quat = d4{bq[0], bq[1], bq[2], bq[3]};
-      pos = d3{bp[0], bp[1], bp[2]};
-      int h = body_hinge[lane];
-      if (h >= 0) {
-        const double* ax = sm + L.o.axis + 3 * lane;
-        const double* sc = sm + L.o.hsc + 2 * h;       // sin, cos of q[7 + h] / 2 (hinge_sincos / integrate_wave)
+      quat = F.bq;
+      pos = F.bp;
+      if (F.hinge >= 0) {
+        const double* sc = sm + L.o.hsc + 2 * F.hinge;   // sin, cos of q[7 + h] / 2 (hinge_sincos / integrate_wave)
         const double s = sc[0], c = sc[1];
-        quat = qmul(quat, d4{c, ax[0] * s, ax[1] * s, ax[2] * s});
+        quat = qmul(quat, d4{c, F.ax.x * s, F.ax.y * s, F.ax.z * s});
       }
     }
   }
@@ -124,8 +143,10 @@ __device__ __forceinline__ void fk_wave(const LT& L, double* sm, const short* ho
   // lanes of this one wavefront, so a round takes the ancestor's transform straight out of that lane's registers
   // (ds_bpermute: every lane is read as it was BEFORE the round, which is what pointer jumping needs): no staging
   // buffer, no fence, no dependent index -> address -> data chain through LDS.
-  for (int r = 0; r < L.nhop; r++) {
-    const int src = 4 * hop[r * L.o.cap.nb + (lane < nb ? lane : 0)];        // byte address of the source lane
+#pragma unroll
+  for (int r = 0; r < IK_MAX_HOPS; r++) {
+    if (r >= L.nhop) break;
+    const int src = F.src[r];
     const d3 pa = {bpermute_d(src, pos.x), bpermute_d(src, pos.y), bpermute_d(src, pos.z)};
     const d4 qa = {bpermute_d(src, quat.w), bpermute_d(src, quat.x), bpermute_d(src, quat.y), bpermute_d(src, quat.z)};
     if (lane < nb && dep >= (1 << r)) {
@@ -137,9 +158,8 @@ __device__ __forceinline__ void fk_wave(const LT& L, double* sm, const short* ho
     quat = qnormalize(quat);
     double* o = sm + L.o.xa + 7 * lane;
     o[0] = pos.x; o[1] = pos.y; o[2] = pos.z; o[3] = quat.w; o[4] = quat.x; o[5] = quat.y; o[6] = quat.z;
-    if (body_hinge[lane] >= 0) {
-      const double* ax = sm + L.o.axis + 3 * lane;
-      d3 aw = qrot(quat, d3{ax[0], ax[1], ax[2]});
+    if (F.hinge >= 0) {
+      d3 aw = qrot(quat, F.ax);
       double* xa = sm + L.o.xaxis + 3 * lane;
       xa[0] = aw.x; xa[1] = aw.y; xa[2] = aw.z;
     }
@@ -865,7 +885,8 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
   WSYNC();
   hinge_sincos(L, sm, lane);
   WSYNC();
-  fk_wave<NW>(L, sm, hop, depth, body_hinge, lane, pr);
+  const FkLane fkc = fk_lane(L, sm, hop, depth, body_hinge, lane);
+  fk_wave<NW>(L, sm, fkc, lane, pr);
 
   const int Ts = len ? min(len[s], T) : T;
   const size_t fstride = (size_t)nhum * 7;
@@ -947,7 +968,7 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
           }
           if (rc != GMR_STATUS_OK) { stat = rc; break; }
           integrate_wave<NW>(L, sm, prm[5], lane, pr);
-          fk_wave<NW>(L, sm, hop, depth, body_hinge, lane, pr);
+          fk_wave<NW>(L, sm, fkc, lane, pr);
           if (NW > 1) {
             if (lane == 0) { int* c = ctl + 2 * (epoch & 1); c[0] = CMD_JBODY; c[1] = stage; }
             epoch++;
