@@ -339,14 +339,15 @@ __device__ __forceinline__ void jbody_phase(const LT& L, double* sm, int stage, 
 // (b2) all wavefronts, after Jl^-1: Jw[p] = W_k (-Jl^-1(e_k)) Jb[p] in place, and the column's share of c
 template <class LT>
 __device__ __forceinline__ void pairs_from_jbody(const LT& L, double* sm, int stage, const StageTabs& tb, int vlane, int nvl,
-                                                 const uint32_t* zero_off) {
+                                                 const uint32_t* zero_off, int k_first) {
+  // k_first: task of pair `vlane` (the first trip's, read once per launch by the caller; P <= nvl: the only trip)
   const int P = L.P[stage];
   const double* wpos = sm + L.o.wpos[stage];
   const double* wrot = sm + L.o.wrot[stage];
   double* Jw = sm + L.o.Jw;
   double* cpart = sm + L.o.cpart;
   for (int p = vlane; p < P; p += nvl) {
-    const int k = (unsigned short)tb.pair_task[p] & 15u;
+    const int k = p == vlane ? k_first : ((unsigned short)tb.pair_task[p] & 15u);
     double* o = Jw + 6 * p;
     const d3 jl = {o[0], o[1], o[2]}, ja = {o[3], o[4], o[5]};
     const double* M = sm + L.o.M + 18 * k;
@@ -427,7 +428,7 @@ __device__ __forceinline__ void item_add(char* Hb, uint32_t hi, double acc, doub
 
 template <class LT>
 __device__ __forceinline__ void hacc_phase(const LT& L, double* sm, int stage, const StageTabs& tb, double diag,
-                                           int vlane) {
+                                           int vlane, const uint2* first) {   // first: the first trip's items, loaded by the caller
   const int nl = L.nlanes, ntrip = L.ntrip[stage];
   const bool paired = vlane < L.pair_lanes;       // the whole first helper wavefront, or nobody
   char* __restrict__ Hb = reinterpret_cast<char*>(sm + L.o.H);
@@ -436,7 +437,7 @@ __device__ __forceinline__ void hacc_phase(const LT& L, double* sm, int stage, c
   double acc = 0.0;
   uint2 n[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) n[k] = items[k * nl];
+  for (int k = 0; k < 4; k++) n[k] = first[k];
   for (int it = 0; it < ntrip; it += 4) {                  // four slots per trip: their row reads are in flight together
     uint2 w[4];
 #pragma unroll
@@ -509,7 +510,7 @@ template <int NW, class LT>
 __device__ __forceinline__ void build_qp_main(const LT& L, double* sm, int stage, const StageTabs& tb,
                                               const short* hinge_body, const short* limited, int* ctl, int& epoch,
                                               double damping, double lm_damping, double limit_gain, int lane,
-                                              Prof& pr) {
+                                              int pk_main, Prof& pr) {   // pk_main: task of this lane's pair in this table
   double mu = jlog_phase<NW>(L, sm, stage, lm_damping, lane, pr);
   const double diag = damping + mu;
   if (NW == 1) {
@@ -529,7 +530,7 @@ __device__ __forceinline__ void build_qp_main(const LT& L, double* sm, int stage
     if (lane == 0) { int* c = ctl + 2 * (epoch & 1); c[0] = CMD_BUILD; c[1] = stage; (sm + L.o.scal)[0] = diag; }
     epoch++;
     __syncthreads();                      // B1: helpers see the command; M / we and the body Jacobians are final
-    pairs_from_jbody(L, sm, stage, tb, lane, 64 * NW, nullptr);      // (the main wavefront's lanes zero nothing)
+    pairs_from_jbody(L, sm, stage, tb, lane, 64 * NW, nullptr, pk_main);      // (the main wavefront's lanes zero nothing)
     __syncthreads();                      // B2: all Jacobian columns written
     PROF_END(pr, PH_PAIRS);
     PROF_BEGIN(pr);
@@ -549,6 +550,9 @@ __device__ __forceinline__ void helper_loop(const LT& L, double* sm, const uint3
   TreeState bs = {0ull, 0ull};            // bound sets of the QP (identical in every wavefront)
   const TreeRows<16> rows_s = tree_rows<7, 9, false>(L, si, wave, lane);
   const TreeRows<18> rows_l = tree_rows<8, 10, false>(L, si, wave, lane);
+  int pk[2];                              // task of this lane's (task, dof) pair in either table
+#pragma unroll
+  for (int st = 0; st < 2; st++) pk[st] = (unsigned short)(si + L.o.i_pair_task[st])[min(wave * 64 + lane, L.o.cap.p - 1)] & 15u;
   for (int epoch = 0;; epoch++) {         // command n sits in mailbox slot n & 1 (see the main wavefront)
     PROF_BEGIN(hp);
     __syncthreads();                      // B1 (or the EXIT barrier)
@@ -566,14 +570,19 @@ __device__ __forceinline__ void helper_loop(const LT& L, double* sm, const uint3
       continue;
     }
     const double diag = (sm + L.o.scal)[0];
+    // the first trip of this wavefront's H share: constants of the stage, asked for now so that they have arrived when
+    // the barrier after the column phase opens (instead of starting an item -> row -> FMA chain there)
+    uint2 first[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) first[k] = tb.items[k * L.nlanes + (wave - 1) * 64 + lane];
     PROF_BEGIN(hp);
-    pairs_from_jbody(L, sm, stage, tb, wave * 64 + lane, 64 * NW, sw + L.o.w_zero + stage * IK_MAX_ZERO);
+    pairs_from_jbody(L, sm, stage, tb, wave * 64 + lane, 64 * NW, sw + L.o.w_zero + stage * IK_MAX_ZERO, pk[stage]);
     PROF_END(hp, PH_PAIRS);
     PROF_BEGIN(hp);
     __syncthreads();                      // B2
     PROF_END(hp, PH_CVEC);                // wait at B2
     PROF_BEGIN(hp);
-    hacc_phase(L, sm, stage, tb, diag, (wave - 1) * 64 + lane);
+    hacc_phase(L, sm, stage, tb, diag, (wave - 1) * 64 + lane, first);
     PROF_END(hp, PH_HACC);
     PROF_BEGIN(hp);
     __syncthreads();                      // B3
@@ -886,6 +895,9 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
   hinge_sincos(L, sm, lane);
   WSYNC();
   const FkLane fkc = fk_lane(L, sm, hop, depth, body_hinge, lane);
+  int pk_main[2];                         // task of this lane's (task, dof) pair in either table (column phase)
+#pragma unroll
+  for (int st = 0; st < 2; st++) pk_main[st] = (unsigned short)(si + L.o.i_pair_task[st])[lane] & 15u;
   fk_wave<NW>(L, sm, fkc, lane, pr);
 
   const int Ts = len ? min(len[s], T) : T;
@@ -952,7 +964,7 @@ __global__ __launch_bounds__(64 * NW, GMR_IK_MIN_WAVES) void ik_streams_kernel(c
                                                                  : errors_wave<NW>(L, sm, tb.task_body, tb.task_human, K, lane, pr);
         int nsol = 0, num_iter = 0;
         for (;;) {
-          build_qp_main<NW>(L, sm, stage, tb, hinge_body, limited, ctl, epoch, prm[0], prm[1], prm[3], lane, pr);
+          build_qp_main<NW>(L, sm, stage, tb, hinge_body, limited, ctl, epoch, prm[0], prm[1], prm[3], lane, pk_main[stage], pr);
           PROF_COUNT(pr, PH_NSOLVE);
           int rc;
           if (NW > 1) {   // the 4-wavefront shape is only launched for robots that decompose (gmr_abi.hip)
