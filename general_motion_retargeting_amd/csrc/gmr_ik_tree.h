@@ -132,11 +132,21 @@ __device__ __forceinline__ int solve_qp_tree(const LT& L, double* sm, uint32_t* 
     // -c_i - sum over fixed j of H_ij x_j (the bound value of j from the uniform sets)
     rhs0 = row ? (self_fixed ? xfix : -ci) : 0.0;
     if (row && !self_fixed) {
+      // (same terms in the same order, one iteration ahead with the loads: the LDS round trips of the fixed variables
+      //  overlap instead of adding up -- the stream that sets the batch's time has five of them in every solve)
       unsigned long long mm = fixedm;
-      while (mm) {
+      if (mm) {
         int j = __ffsll((long long)mm) - 1;
         mm &= mm - 1;
-        rhs0 -= Hrow[j] * (((bs.lower >> j) & 1ull) ? los[j] : his[j]);
+        double h = Hrow[j], bv = (((bs.lower >> j) & 1ull) ? los : his)[j];
+        while (mm) {
+          const int jn = __ffsll((long long)mm) - 1;
+          mm &= mm - 1;
+          const double hn = Hrow[jn], bn = (((bs.lower >> jn) & 1ull) ? los : his)[jn];
+          rhs0 -= h * bv;
+          h = hn; bv = bn;
+        }
+        rhs0 -= h * bv;
       }
     }
     b = is_limb ? rhs0 : 0.0;
