@@ -370,16 +370,26 @@ __device__ __forceinline__ int solve_rows(const WideDims& D, double* sm, const c
     // -c_i - sum over fixed j of H_ij x_j (the bound value of j from the uniform sets)
     double rhs0 = row ? (self_fixed ? xfix : -ci) : 0.0;
     {
-      unsigned long long mm = fixedm;
-      while (mm) {
-        const int j = __ffsll((long long)mm) - 1;               // owner lane of a fixed variable (wave-uniform)
-        mm &= mm - 1;
+      // (one iteration ahead with the loads: the round trips of the fixed variables overlap; same terms, same order)
+      auto term = [&](int j, double& coef, double& bj) {        // j: owner lane of a fixed variable (wave-uniform)
         const int dj = tree[j];
-        const double bj = ((bs.lower >> j) & 1ull) ? los[dj] : his[dj];
+        bj = ((bs.lower >> j) & 1ull) ? los[dj] : his[dj];
         const int jr = j & 15, lj = j >> 4;
-        double coef;
         if (jr < NL) coef = is_limb ? (grp == lj ? LMrow[jr] : 0.0) : H[7 * (16 * lj + lane) + jr];
         else coef = is_limb ? H[7 * (16 * grp + jr) + a] : Trow[jr - NL];
+      };
+      unsigned long long mm = fixedm;
+      if (mm) {
+        double coef, bj;
+        term(__ffsll((long long)mm) - 1, coef, bj);
+        mm &= mm - 1;
+        while (mm) {
+          double cn, bn;
+          term(__ffsll((long long)mm) - 1, cn, bn);
+          mm &= mm - 1;
+          if (row && !self_fixed) rhs0 -= coef * bj;
+          coef = cn; bj = bn;
+        }
         if (row && !self_fixed) rhs0 -= coef * bj;
       }
     }
