@@ -10,9 +10,13 @@ timed region is K steps after W warm-up steps, bracketed by a barrier + device s
 N = 1 (default)  `value` = BASELINE.json configs[1]: the 10k-frame batch, S=100 streams x T=100 frames (SURVEY.md
                  section 8d "Config 2"), with the roofline object of its kernel and the CPU baseline timed on this
                  box's host cores.  Beside it, `strong_1m`: the 1M-frame batch of the multi-GPU leg on this one GPU.
-N > 1            (launched by `python -m torch.distributed.run`, one rank per GPU; the launcher only provides
-                 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*: the ranks talk through the library's own RCCL communicator,
-                 no PyTorch)  `value` = the 1M-frame synthetic batch north_star names -- S=131072 streams x T=8
+N > 1            one rank per GPU.  Either launched by `python -m torch.distributed.run` (the launcher only provides
+                 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), or plainly as `python bench.py --gpus N`: with WORLD_SIZE
+                 unset the process becomes the LAUNCHER -- it never loads the library or touches a GPU, starts N fresh
+                 rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / two free
+                 ports), relays rank 0's JSON line and exits non-zero as soon as any rank does (the others are
+                 killed; GMR_BENCH_TIMEOUT bounds the whole job).  The ranks talk through the library's own RCCL
+                 communicator, no PyTorch.  `value` = the 1M-frame synthetic batch north_star names -- S=131072 streams x T=8
                  frames, the same seeds for every N (wide enough that one of 8 GPUs still holds 16 384 streams: measured
                  on one GPU, 16 384 streams run at 0.91 of the rate of 131 072, 8 192 x 16 only at 0.83 of 65 536 x 16:
                  the tail of the longest streams, no communication involved) -- LPT-sharded over the N GPUs after ONE
@@ -64,6 +68,108 @@ F_ERR = {"unitree_g1": 2.1e3}
 METRIC = "retargeted frames/sec (whole node) + max joint-angle err vs CPU ref, G1 29-DoF"
 
 
+def _free_ports(n):
+    import socket
+    socks, ports = [], []
+    for _ in range(n):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        socks.append(s)
+        ports.append(s.getsockname()[1])
+    for s in socks:
+        s.close()
+    return ports
+
+
+def self_launch(n: int, argv) -> int:
+    """`python bench.py --gpus N` without an external launcher: this process starts N rank processes of this script
+    and does nothing else -- in particular it never loads libgmrhip.so and never initialises a GPU.  Rank 0's stdout
+    (the ONE JSON line) is relayed; the first non-zero exit of any rank ends the job with that code (the remaining
+    ranks are terminated by PID)."""
+    import signal
+    import subprocess
+    port, comm_port = _free_ports(2)
+    timeout = float(os.environ.get("GMR_BENCH_TIMEOUT", "1500"))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GMR_COMM_PORT=str(comm_port), GMR_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
+        env.setdefault("GMR_COMM_TIMEOUT", "120")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, start_new_session=True))
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)        # each rank is its own session: its generator workers go with it
+                except OSError:
+                    pass
+        t_kill = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(max(0.1, t_kill - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+
+    import threading
+    lines = []
+
+    def relay():
+        for raw in procs[0].stdout:
+            line = raw.decode(errors="replace")
+            lines.append(line)
+            sys.stdout.write(line)
+            sys.stdout.flush()
+
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    t_end = time.time() + timeout
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                r, c = bad[0]
+                print(f"[bench launcher] rank {r} exited with code {c}: stopping the other ranks", file=sys.stderr, flush=True)
+                rc = c if c > 0 else 1
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > t_end:
+                print(f"[bench launcher] no result within GMR_BENCH_TIMEOUT={timeout:.0f} s: stopping all ranks", file=sys.stderr, flush=True)
+                rc = 124
+                break
+            time.sleep(0.05)
+    finally:
+        stop_all()
+    th.join(5.0)
+    if rc == 0 and not any(ln.lstrip().startswith("{") for ln in lines):
+        print("[bench launcher] every rank exited 0 but rank 0 printed no JSON line", file=sys.stderr, flush=True)
+        rc = 1
+    return rc
+
+
+def load_standin():
+    """GMR_BENCH_STANDIN=/path/to/file.py: a module that provides `init(local_rank)`, `Solver(model_blob, taskset_blob)`,
+    `Shard(solver, q0, human)`, `Event()` and `device_sync()` in place of the HIP ones -- the CPU rehearsal of the
+    launcher and of the N > 1 protocol in tests/ (no GPU there).  Never set on a GPU box; the line says `"standin"`."""
+    path = os.environ.get("GMR_BENCH_STANDIN")
+    if not path:
+        return None
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gmr_bench_standin", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 class Shard:
     """One batch of streams resident on this rank's GPU + the function that retargets it once."""
 
@@ -110,11 +216,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (before anything loads the library or touches a GPU)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank, local_rank, world = gcomm.env_rank_world()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: running {world}", file=sys.stderr)
         args.gpus = world
+    standin = load_standin()
 
     model = load_robot(params.ROBOT_XML_DICT[args.robot])
     tt = build_task_tables(load_ik_config(params.IK_CONFIG_DICT[args.src][args.robot]), None)
@@ -142,13 +252,28 @@ def main():
     # No torch in this process unless a torch backend is asked for: bind the library to the SYSTEM HIP runtime, the one
     # the system's librccl.so is linked against (with torch installed, _lib would otherwise preload torch's bundled copy
     # so that a later `import torch` shares it: two HIP runtimes in one process is what that avoids, here as there).
-    if (os.environ.get("GMR_BENCH_BACKEND") or os.environ.get("GMR_COMM_BACKEND") or "rccl").lower() == "rccl":
+    if (os.environ.get("GMR_BENCH_BACKEND") or os.environ.get("GMR_COMM_BACKEND") or "rccl").lower() in ("rccl", "tcp"):
         os.environ.setdefault("GMR_HIP_RUNTIME", "system")
-    L = _lib.lib()
-    _lib.require_gpu()
-    _lib.check(L.gmr_set_device(local_rank % max(L.gmr_device_count(), 1)))
+    # A job whose RCCL bring-up fails (agreed by all ranks over the control star) still yields a scaling curve: it
+    # continues on the star and `comm_backend` says "tcp (fallback: <reason>)".  GMR_COMM_FALLBACK=none makes it fatal.
+    os.environ.setdefault("GMR_COMM_FALLBACK", "tcp")
+    if standin is None:
+        L = _lib.lib()
+        _lib.require_gpu()
+        _lib.check(L.gmr_set_device(local_rank % max(L.gmr_device_count(), 1)))
+        SolverCls, ShardCls, EventCls, device_sync = _lib.Solver, Shard, _lib.Event, sharding._device_sync
+    else:
+        standin.init(local_rank)
+        SolverCls, ShardCls, EventCls, device_sync = standin.Solver, standin.Shard, standin.Event, standin.device_sync
     # GMR_BENCH_FORCE_DIST=1 with ONE rank walks the whole RCCL path (init, broadcast, barrier, reductions) on one GPU
-    comm = gcomm.create(os.environ.get("GMR_BENCH_BACKEND"), force=os.environ.get("GMR_BENCH_FORCE_DIST") == "1")
+    try:
+        comm = gcomm.create(os.environ.get("GMR_BENCH_BACKEND"), force=os.environ.get("GMR_BENCH_FORCE_DIST") == "1")
+    except Exception as e:      # the same error on every rank (comm.py): say it once per rank and leave non-zero
+        print(f"[bench] rank {rank}: communicator could not be created: {e}", file=sys.stderr, flush=True)
+        raise SystemExit(3)
+    if comm.world != world or comm.rank != rank:
+        print(f"[bench] rank {rank}: communicator reports rank {comm.rank} of {comm.world}, launcher said {rank} of {world}", file=sys.stderr)
+        raise SystemExit(3)
 
     # ---- rank 0 compiles the robot + task set; ONE broadcast ships it to the peers -----------------------------------
     mb0 = ts0 = None
@@ -156,14 +281,14 @@ def main():
         mb0, ts0 = pack_model(model), pack_taskset(model, tt)
     mb, ts = sharding.broadcast_blobs(mb0, ts0, rank, comm)      # RCCL over xGMI, ~24 KB, once
     assert mb.dtype == MODEL_DTYPE and ts.dtype == TASKSET_DTYPE
-    solver = _lib.Solver(mb, ts)
+    solver = SolverCls(mb, ts)
 
     # ---- leg A: BASELINE.json configs[1] (per rank) -------------------------------------------------------------------
-    shard = Shard(solver, q0, human)
+    shard = ShardCls(solver, q0, human)
     for _ in range(args.warmup):
         shard.step()
     comm.barrier()
-    evs = [(_lib.Event(), _lib.Event()) for _ in range(args.steps)]
+    evs = [(EventCls(), EventCls()) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
         shard.step(*evs[i])
@@ -182,18 +307,18 @@ def main():
         keep = {}
 
         def make_step(ids):
-            keep["mine"] = Shard(solver, q_mine, h_mine)
+            keep["mine"] = ShardCls(solver, q_mine, h_mine)
             return keep["mine"].step
 
         def single_step():
             keep["mine"].free()
-            keep["all"] = Shard(solver, q_all, h_all)
+            keep["all"] = ShardCls(solver, q_all, h_all)
             return keep["all"].step
 
         # N > 1: `value` -> exactly K steps; N = 1: an extra beside configs[1], kept short
         k_strong = args.steps if world > 1 else max(1, min(args.steps, 5))
         sres = sharding.strong_scaling_leg(comm, lens, make_step, k_strong, min(args.warmup, 1),
-                                           single_step if world > 1 else None)
+                                           single_step if world > 1 else None, device_sync=device_sync)
         last = keep.get("all") or keep["mine"]
         _, ns_s, st_s = last.results()
         assert (st_s == 0).all(), "IK kernel reported a failed stream (1M-frame leg)"
@@ -264,13 +389,17 @@ def main():
                 "config": {
                     "workload": f"1M-frame synthetic AMASS-shaped batch -> Unitree G1 (29-DoF): S={SS} streams x T={ST} frames "
                                 f"= {SS * ST} frames in total, LPT-sharded over {world} GPU(s), the same seeds for every N "
-                                f"(north_star; BASELINE.json configs[3] shape on one robot)",
+                                f"(north_star; BASELINE.json configs[3] shape on one robot).  `value` at N > 1 is THIS strong-"
+                                f"scaling batch; its one-GPU anchor is `value_1gpu` here (same run, rank 0's GPU) = "
+                                f"`strong_1m.value` of the N = 1 line -- NOT the N = 1 line's `value`, which is configs[1] "
+                                f"(10k frames, latency shape; repeated here per rank as `weak_leg`)",
                     "robot": args.robot, "source": args.src, "streams": SS, "frames_per_stream": ST,
                     "parallelism": f"streams sharded over {world} GPU(s): one {comm.backend} broadcast of the 24 KB model + "
                                    f"task set, no per-step collective",
                     "mean_solves_per_frame": sres["mean_solves_per_frame"],
                 },
-                "world_size": sres["world_size"], "comm_backend": comm.backend,
+                "world_size": comm.world, "world_size_launcher": world, "comm_backend": comm.backend,
+                "launcher": "self (bench.py --gpus N)" if os.environ.get("GMR_BENCH_SELF_LAUNCHED") == "1" else "external (RANK / WORLD_SIZE from the environment)",
                 "frames_per_rank": sres["frames_per_rank"],
                 "per_rank_ms_per_step": [t / sres["steps"] * 1e3 for t in sres["per_rank_seconds"]],
                 "value_1gpu": sres.get("value_1gpu"), "efficiency": sres.get("efficiency"),
@@ -283,7 +412,10 @@ def main():
                     "roofline": roofline,
                 },
             })
-        if not args.no_cpu_baseline and world == 1:
+        if standin is not None:
+            out["standin"] = os.environ["GMR_BENCH_STANDIN"]
+            out["data"] = "synthetic (STAND-IN compute function: rehearsal of the launcher / N > 1 protocol, not a measurement)"
+        if not args.no_cpu_baseline:
             from oracle import oracle as orc   # CPU restatement: the checker and the timed CPU leg
             orc.build()
             cores = os.cpu_count() or 1
@@ -303,8 +435,8 @@ def main():
                 "unit": "frames/s",
                 "cores": cores,
                 "kind": "port",
-                "sample": f"the same S={S}xT={T} batch, OpenMP over streams on {cores} host threads; "
-                          f"1-thread rate on the first {s1} streams: {s1 * T / cpu1_s:.0f} frames/s",
+                "sample": f"the same S={S}xT={T} batch (rank 0's shard of configs[1]), OpenMP over streams on {cores} host "
+                          f"threads; 1-thread rate on the first {s1} streams: {s1 * T / cpu1_s:.0f} frames/s",
                 "note": "C restatement of mink/MuJoCo/DAQP (oracle/gmr_oracle.c); the genuine reference cannot run offline "
                         "(published: 35-70 frames/s single stream, README.md:217-220).  Parity of the restatement with the "
                         "genuine stack is unpinned for the IK numerics; the one known difference (DAQP stops at ~1e-6 primal "

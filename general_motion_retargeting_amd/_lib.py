@@ -73,6 +73,7 @@ _SIGS = {
     "gmr_comm_destroy": (C.c_int, [C.c_void_p]),
     "gmr_comm_rank": (C.c_int, [C.c_void_p]),
     "gmr_comm_world": (C.c_int, [C.c_void_p]),
+    "gmr_comm_backend": (C.c_char_p, [C.c_void_p]),
     "gmr_comm_broadcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "gmr_comm_broadcast_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "gmr_comm_barrier": (C.c_int, [C.c_void_p]),

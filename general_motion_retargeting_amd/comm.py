@@ -4,8 +4,12 @@ per-step collective.
 
 Backends behind one small interface (:func:`create`):
 
-* ``"rccl"``  -- the library's own communicator (``gmr_comm_*``: RCCL opened with dlopen, ncclUniqueId exchanged over a
-  TCP socket at ``MASTER_ADDR``; no PyTorch).  The default when more than one rank runs on GPUs.
+* ``"rccl"``  -- the library's own communicator (``gmr_comm_*``: RCCL opened with dlopen, the ranks form a TCP control
+  star at ``MASTER_ADDR`` over which the ncclUniqueId travels and every bring-up step is agreed on; no PyTorch).  The
+  default when more than one rank runs on GPUs.  A failure is the same :class:`GmrHipError` on EVERY rank (there is no
+  silent per-rank fallback: a rank that switched backends alone would leave its peers in a rendezvous nobody joins);
+  ``GMR_COMM_FALLBACK=tcp`` lets the whole job continue on the control star instead, labelled as such.
+* ``"tcp"``   -- the control star alone (job-level plumbing only; CPU rehearsal of the N>1 path without torch).
 * ``"torch"`` -- ``torch.distributed`` (``nccl`` = RCCL on ROCm, or ``gloo`` for the CPU rehearsal of the N>1 path in
   the test-suite): optional plumbing for callers that already live in a torch process group.
 * ``"none"``  -- a single rank.
@@ -39,7 +43,8 @@ class SingleComm:
 
     def barrier(self):
         from . import _lib
-        _lib.check(_lib.lib().gmr_stream_sync(None))
+        if _lib.lib().gmr_device_count() > 0:        # (a CPU-only rehearsal has nothing to wait for)
+            _lib.check(_lib.lib().gmr_stream_sync(None))
 
     def allreduce_max(self, x: float) -> float:
         return float(x)
@@ -52,17 +57,29 @@ class SingleComm:
 
 
 class RcclComm:
-    """``gmr_comm_*`` of libgmrhip.so.  Call after ``gmr_set_device(local_rank)``."""
-    backend = "rccl"
+    """``gmr_comm_*`` of libgmrhip.so.  Call after ``gmr_set_device(local_rank)``.  ``backend`` is what the library
+    reports: ``"rccl-<version>"``, ``"tcp"`` or ``"tcp (fallback: ...)"``."""
 
-    def __init__(self, rank: int, world: int, addr: Optional[str] = None, port: Optional[int] = None):
+    def __init__(self, rank: int, world: int, addr: Optional[str] = None, port: Optional[int] = None, tcp: bool = False):
         from . import _lib
         self._lib = _lib
         h = C.c_void_p()
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
-        _lib.check(_lib.lib().gmr_comm_create(rank, world, addr.encode(), int(port or default_port()), C.byref(h)))
+        saved = os.environ.get("GMR_COMM_BACKEND")
+        if tcp:
+            os.environ["GMR_COMM_BACKEND"] = "tcp"         # read by gmr_comm_create
+        elif saved == "tcp":
+            del os.environ["GMR_COMM_BACKEND"]
+        try:
+            _lib.check(_lib.lib().gmr_comm_create(rank, world, addr.encode(), int(port or default_port()), C.byref(h)))
+        finally:
+            if saved is None:
+                os.environ.pop("GMR_COMM_BACKEND", None)
+            else:
+                os.environ["GMR_COMM_BACKEND"] = saved
         self.handle = h
         self.rank, self.world = rank, world
+        self.backend = _lib.lib().gmr_comm_backend(h).decode()
 
     def broadcast_bytes(self, buf, nbytes, root=0):
         out = np.zeros(nbytes, dtype=np.uint8) if buf is None else np.ascontiguousarray(buf, dtype=np.uint8).copy()
@@ -145,20 +162,17 @@ class TorchComm:
 
 def create(backend: Optional[str] = None, force: bool = False):
     """Communicator of this process from the launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
-    ``backend``: "rccl" (default for world > 1), "torch" / "torch-nccl", "gloo" / "torch-gloo", "none".
-    ``force``: build a real communicator even for a single rank (rehearsal of the N>1 path on one GPU)."""
+    ``backend``: "rccl" (default for world > 1), "tcp", "torch" / "torch-nccl", "gloo" / "torch-gloo", "none".
+    ``force``: build a real communicator even for a single rank (rehearsal of the N>1 path on one GPU).
+    A failure raises on every rank (see the module docstring); start a fresh job with another backend if wanted."""
     rank, local_rank, world = env_rank_world()
     backend = (backend or os.environ.get("GMR_COMM_BACKEND") or "rccl").lower()
     if backend == "none" or (world == 1 and not force):
         return SingleComm()
     if backend == "rccl":
-        try:
-            return RcclComm(rank, world)
-        except Exception as e:                       # e.g. the bootstrap port is taken: keep the job alive
-            import sys
-            print(f"[gmr comm] native RCCL communicator failed on rank {rank} ({e}); falling back to torch.distributed",
-                  file=sys.stderr, flush=True)
-            return TorchComm(rank, local_rank, world, "nccl")
+        return RcclComm(rank, world)
+    if backend == "tcp":
+        return RcclComm(rank, world, tcp=True)
     if backend in ("torch", "torch-nccl", "nccl"):
         return TorchComm(rank, local_rank, world, "nccl")
     if backend in ("gloo", "torch-gloo"):

@@ -366,8 +366,10 @@ int gmr_retarget_streams(gmr_solver_t* s, int S, int T, const double* q0, const 
              (len && (e = hipMemcpyAsync(d + o_len, len, b_len, hipMemcpyHostToDevice, nullptr)) != hipSuccess)) {
     rc = fail(GMR_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
   }
-  // frames at or beyond len[s] are not touched by the kernel: hand them back as zeros
-  if (rc == GMR_OK && len && (e = hipMemsetAsync(d + o_qo, 0, out_bytes, nullptr)) != hipSuccess)
+  // frames at or beyond len[s] are not touched by the kernel, nor are the tgt_out / err_out rows of the frames after a
+  // stream's status turned non-OK (err_out: including the failing frame): hand them back as zeros, never as what an
+  // earlier call left in the grow-only workspace
+  if (rc == GMR_OK && (len || tgt_out || err_out) && (e = hipMemsetAsync(d + o_qo, 0, out_bytes, nullptr)) != hipSuccess)
     rc = fail(GMR_ERR_HIP, "memset: %s", hipGetErrorString(e));
   if (rc == GMR_OK)
     rc = gmr_retarget_streams_dev(s, S, T, (double*)(d + o_q0), (double*)(d + o_h), len ? (int32_t*)(d + o_len) : nullptr,

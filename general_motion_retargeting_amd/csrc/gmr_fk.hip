@@ -54,8 +54,12 @@ __device__ __forceinline__ void qrot_xyzw(f4 q, float vx, float vy, float vz, fl
 
 // sin and cos of a joint half angle (|x| of a few radians): Cody-Waite reduction by pi/2 in three pieces, the Cephes
 // single-precision kernels on [-pi/4, pi/4] (~1 ulp).  28 instructions instead of the 125 of the library call (which
-// carries a large-argument path); explicit fmaf, so `fp contract(off)` does not change it.
+// carries a large-argument path); explicit fmaf, so `fp contract(off)` does not change it.  The three-piece reduction is
+// exact only while k * 1.5703125 is (|k| < 2^13): beyond |x| = 1000 rad -- forward_kinematics accepts any user angle,
+// torch.sin / torch.cos are accurate for all of them -- and for NaN / Inf (where `(int)k` would be undefined) the
+// library call is taken: a wave-rare branch.
 __device__ __forceinline__ void sincosf_small(float x, float* sn, float* cs) {
+  if (!(fabsf(x) <= 1000.0f)) { sincosf(x, sn, cs); return; }
   const float k = rintf(x * 0.636619772367581343f);
   float r = fmaf(-k, 1.5703125f, x);
   r = fmaf(-k, 4.837512969970703125e-4f, r);

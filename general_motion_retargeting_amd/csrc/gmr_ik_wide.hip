@@ -961,8 +961,9 @@ extern "C" hipError_t gmr_launch_ik_wide(const char* d_image, const gmr::WideLay
   gmr::wide::WideQueue Q{nullptr, nullptr, nullptr, 0};
   int grid = S, chunk = 0;
   if (p) { std::lock_guard<std::mutex> g(p->mu); chunk = p->chunk; }
-  // the ring has one entry per chunk: very long jobs get longer chunks rather than a ring beyond 64 MB
-  while (chunk > 0 && (long long)S * ((T + chunk - 1) / chunk) > (1ll << 24)) chunk *= 2;
+  // the ring has one entry per chunk: very long jobs get longer chunks rather than a ring beyond 64 MB (more than 2^24
+  // streams cannot be helped by longer chunks: the loop ends at chunk >= T and the launch below is a direct one)
+  while (chunk > 0 && chunk < T && (long long)S * ((T + chunk - 1) / chunk) > (1ll << 24)) chunk *= 2;
   // queued mode pays only when streams outnumber the resident wavefronts and have more than one chunk
   if (p && !d_prof && chunk > 0 && p->slots > 0 && T > chunk && (long long)S > (long long)p->slots * p->min_streams_per_slot) {
     const size_t nring = (size_t)S * (size_t)((T + chunk - 1) / chunk);

@@ -106,6 +106,10 @@ int gmr_solver_set_dispatch(gmr_solver_t* solver, int frames_per_item);
  *                                  computed them (absent bodies stay NaN rows)
  *   err_out f64 [S][T][2]          or NULL: error1() / error2() (:188-200) at the configuration each frame
  *                                  ends with (0 for a stage the config does not use)
+ * Rows the kernel does not write: frames at or beyond len[s]; and, for a stream whose status is not GMR_STATUS_OK,
+ * the tgt_out rows of the frames AFTER the failing one and the err_out rows from the failing frame on (q_out keeps the
+ * last good configuration for those frames, nsolve 0).  The host entry point returns such rows as zeros; the device
+ * entry point leaves the caller's memory untouched there -- clear tgt_out / err_out first if stale bytes matter.
  */
 int gmr_retarget_streams_dev(gmr_solver_t* solver, int S, int T, const double* d_q0, const double* d_human,
                              const int32_t* d_len, int flags, double* d_q_out, int32_t* d_nsolve,
@@ -165,10 +169,16 @@ int gmr_smplx_align(gmr_smplx_t* h, int N, int jstride, const float* full_pose, 
  * streams shard over the ranks of one node and the only data that crosses ranks is the packed robot model + task set.
  * RCCL is opened at run time (dlopen of librccl.so; GMR_RCCL_LIBRARY overrides); no PyTorch involved. */
 typedef struct gmr_comm gmr_comm_t;
-/* Rank 0 creates the ncclUniqueId and serves it to the peers over a TCP socket at master_addr:port (the launcher's
- * MASTER_ADDR and a port derived from MASTER_PORT), then every rank joins the communicator.  Call after
- * gmr_set_device(local_rank). */
+/* The ranks form a control star over TCP at master_addr:port (the launcher's MASTER_ADDR and a port derived from
+ * MASTER_PORT); rank 0's ncclUniqueId travels over it and every step of the RCCL bring-up is agreed on by ALL ranks,
+ * so a failure on one rank is the same error (GMR_ERR_COMM, gmr_last_error names the rank and the reason) on every
+ * rank -- never a hang in a half-formed communicator.  Call after gmr_set_device(local_rank).
+ * Environment: GMR_COMM_BACKEND=tcp -- the star alone carries the (job-level, host-buffer) operations below: the CPU
+ * rehearsal of the N > 1 path; GMR_COMM_FALLBACK=tcp -- a job whose RCCL bring-up fails continues on the star, decided
+ * collectively, and gmr_comm_backend() says so; GMR_COMM_TIMEOUT (s, default 120) bounds the rendezvous. */
 int gmr_comm_create(int rank, int world, const char* master_addr, int port, gmr_comm_t** out);
+/* "rccl-<version>", "tcp" or "tcp (fallback: <why RCCL could not be brought up>)"; valid until gmr_comm_destroy */
+const char* gmr_comm_backend(const gmr_comm_t* comm);
 int gmr_comm_destroy(gmr_comm_t* comm);
 int gmr_comm_rank(const gmr_comm_t* comm);
 int gmr_comm_world(const gmr_comm_t* comm);

@@ -15,6 +15,9 @@ is importable in the build container:
 * G-FKAUX -- the remaining public methods of ``KinematicsModel`` (``dof_to_rot``, ``rot_to_dof``,
   ``convert_local_rot_to_global``, ``forward_kinematics(fitted_shape=...)``, :172-246) for two robots.
 
+* G-FKLARGE -- ``forward_kinematics`` on unwrapped angles up to 1e5 rad and on NaN / Inf angles (ADVICE round 2:
+  the kernel's small-argument sincos must not be used there).
+
 * G-BVH  -- the reference's LAFAN1 loader (``utils/lafan1.py`` + ``utils/lafan_vendor``, NumPy/SciPy
   only) on ``tests/golden/synthetic.bvh`` (a 22-joint, 12-frame BVH authored by this repository).
   This pins the "next" row N2.
@@ -196,6 +199,32 @@ def make_fk():
 
 
 
+def make_fk_large():
+    """G-FKLARGE: ``forward_kinematics`` accepts ANY user angle (``rot_to_dof`` clamps, FK does not): unwrapped angles of
+    a few hundred to a few thousand radians, and one frame with a NaN and an Inf angle.  torch.sin / torch.cos are
+    accurate for all of them; a kernel with a small-argument sincos must take another path there."""
+    import torch
+    params = _load_ref_module("params")
+    km = _load_ref_module("kinematics_model")
+    out = {}
+    for i, robot in enumerate(["unitree_g1", "fourier_n1"]):
+        model = km.KinematicsModel(str(params.ROBOT_XML_DICT[robot]), device="cpu")
+        rng = np.random.default_rng(2700 + i)
+        B = 12
+        scale = np.array([3.0, 30.0, 300.0, 900.0, 1100.0, 3000.0, 2.0e4, 1.0e5, 1.0, 400.0, 400.0, 400.0])[:, None]
+        dof = (scale * rng.uniform(-1, 1, size=(B, model.num_dof))).astype(np.float32)
+        dof[9, 2] = np.nan                      # the frames' bodies below joint 2 / 5 become NaN in the reference too
+        dof[10, 5] = np.inf
+        root_pos = rng.normal(size=(B, 3)).astype(np.float32)
+        rq = rng.normal(size=(B, 4))
+        root_rot = (rq / np.linalg.norm(rq, axis=1, keepdims=True)).astype(np.float32)
+        bp, br = model.forward_kinematics(torch.from_numpy(root_pos), torch.from_numpy(root_rot), torch.from_numpy(dof))
+        out[f"{robot}__dof"], out[f"{robot}__root_pos"], out[f"{robot}__root_rot"] = dof, root_pos, root_rot
+        out[f"{robot}__body_pos"], out[f"{robot}__body_rot"] = bp.numpy(), br.numpy()
+    np.savez_compressed(OUT / "g_fk_large.npz", **out)
+    print("g_fk_large.npz:", len(out), "arrays")
+
+
 def make_fk_aux():
     """G-FKAUX: the other public methods of the reference's ``KinematicsModel`` (kinematics_model.py:172-246):
     ``dof_to_rot``, ``rot_to_dof``, ``convert_local_rot_to_global`` and ``forward_kinematics(fitted_shape=...)``,
@@ -317,8 +346,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "fk_aux":
         make_fk_aux()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "fk_large":
+        make_fk_large()
+        sys.exit(0)
     make_pre()
     make_fk()
     make_fk_aux()
+    make_fk_large()
     make_bvh()
     make_smplx()

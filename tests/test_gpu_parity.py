@@ -145,6 +145,23 @@ def test_fk_batch_matches_oracle_and_golden(hip, oracle):
         assert np.abs(bp - obp).max() <= 2e-6 and np.abs(br - obr).max() <= 2e-6
 
 
+@pytest.mark.parametrize("robot", ["unitree_g1", "fourier_n1"])
+def test_fk_large_and_nonfinite_angles_match_reference(hip, robot):
+    """Unwrapped angles up to 1e5 rad and NaN / Inf angles (g_fk_large.npz, reference outputs): the kernel's
+    small-argument sincos hands such lanes to the library path; NaNs exactly where the reference has them."""
+    import os
+    from conftest import GOLDEN
+    from general_motion_retargeting_amd import params
+    from general_motion_retargeting_amd.models import load_kinematics_tree
+    G = np.load(os.path.join(GOLDEN, "g_fk_large.npz"))
+    fk = hip.FkHandle(load_kinematics_tree(params.ROBOT_XML_DICT[robot]))
+    for want_rot in (True, False):
+        bp, br, _ = fk.fk(G[robot + "__root_pos"], G[robot + "__root_rot"], G[robot + "__dof"], want_rot=want_rot)
+        for got, ref in ((bp, G[robot + "__body_pos"]),) + (((br, G[robot + "__body_rot"]),) if want_rot else ()):
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            assert np.nanmax(np.abs(got - ref)) <= 4e-6
+
+
 def test_fk_batch_large_and_edge_sizes(hip, oracle):
     from general_motion_retargeting_amd import params
     from general_motion_retargeting_amd.models import load_kinematics_tree
