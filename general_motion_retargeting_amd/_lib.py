@@ -53,6 +53,12 @@ _SIGS = {
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gmr_retarget_streams": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gmr_retarget_group_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "gmr_retarget_group": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "gmr_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "gmr_host_free": (C.c_int, [C.c_void_p]),
+    "gmr_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "gmr_host_unregister": (C.c_int, [C.c_void_p]),
     "gmr_fk_create": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.POINTER(C.c_void_p)]),
     "gmr_fk_destroy": (C.c_int, [C.c_void_p]),
@@ -196,6 +202,108 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+class _PinnedOwner:
+    """Keeps one gmr_host_alloc block alive for the NumPy arrays that view it."""
+
+    def __init__(self, nbytes: int):
+        p = C.c_void_p()
+        check(lib().gmr_host_alloc(C.byref(p), max(int(nbytes), 8)))
+        self.ptr, self.nbytes = p, int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().gmr_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
+    """``np.empty`` in page-locked host memory (gmr_host_alloc): H2D / D2H copies of such arrays are asynchronous and run
+    at PCIe speed, which is what lets :func:`retarget_group` overlap them with the kernels.  The block is freed when the
+    last view of the array dies."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+    owner = _PinnedOwner(n * dtype.itemsize)
+    buf = (C.c_char * max(owner.nbytes, 1)).from_address(owner.ptr.value)
+    buf._gmr_owner = owner                               # the ctypes buffer is the ndarray's base: it carries the owner
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
+def pinned_copy(a: np.ndarray) -> np.ndarray:
+    out = pinned_empty(a.shape, a.dtype)
+    np.copyto(out, a)
+    return out
+
+
+class Job(C.Structure):
+    """``gmr_job_t``: one (solver, batch) of a group launch."""
+    _fields_ = [("solver", C.c_void_p), ("S", C.c_int32), ("T", C.c_int32), ("q0", C.c_void_p), ("human", C.c_void_p),
+                ("len", C.c_void_p), ("q_out", C.c_void_p), ("nsolve", C.c_void_p), ("status", C.c_void_p),
+                ("tgt_out", C.c_void_p), ("err_out", C.c_void_p)]
+
+
+def _addr(x):
+    """address of a host ndarray / DeviceBuffer / raw pointer / None"""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    if isinstance(x, DeviceBuffer):
+        return x.ptr.value
+    return x.value if isinstance(x, C.c_void_p) else int(x)
+
+
+def retarget_group(jobs, flags: int = 0, slices: int = 0, out_pinned: bool = False):
+    """Several (solver, batch) jobs as ONE scheduling domain through host buffers (``gmr_retarget_group``): the mixed-robot
+    batch of BASELINE.json configs[3].  ``jobs`` = list of dicts ``{"solver": Solver, "human": f64[S,T,nhuman,7], optional
+    "q0": f64[S,nq] (default the solver's qpos0), "lens": i32[S]}``.  Returns one ``(q_out, nsolve, status)`` per job.
+    Inputs in pinned memory (:func:`pinned_empty`) and ``out_pinned=True`` make the copies asynchronous, so that they
+    overlap the kernels slice by slice."""
+    arr = (Job * max(len(jobs), 1))()
+    keep, outs = [], []
+    empty = pinned_empty if out_pinned else (lambda shape, dtype: np.empty(shape, dtype))
+    for i, j in enumerate(jobs):
+        sol = j["solver"]
+        human = j["human"]
+        if not (isinstance(human, np.ndarray) and human.dtype == np.float64 and human.flags.c_contiguous):
+            human = np.ascontiguousarray(human, dtype=np.float64)
+        if human.ndim != 4 or human.shape[2] != sol.nhuman or human.shape[3] != 7:
+            raise ValueError(f"job {i}: human must be [S,T,{sol.nhuman},7], got {human.shape}")
+        S, T = human.shape[:2]
+        q0 = j.get("q0")
+        if q0 is None:
+            q0 = np.broadcast_to(sol.model_blob["qpos0"][0][: sol.nq], (S, sol.nq))
+        q0 = np.ascontiguousarray(q0, dtype=np.float64)
+        if q0.shape != (S, sol.nq):
+            raise ValueError(f"job {i}: q0 must be [{S},{sol.nq}]")
+        lens = j.get("lens")
+        if lens is not None:
+            lens = np.ascontiguousarray(lens, dtype=np.int32)
+            if lens.shape != (S,):
+                raise ValueError(f"job {i}: lens must be [S]")
+        q_out = empty((S, T, sol.nq), np.float64)
+        nsolve = empty((S, T, 2), np.int32)
+        status = np.zeros(S, dtype=np.int32)
+        keep.append((human, q0, lens))
+        outs.append((q_out, nsolve, status))
+        arr[i] = Job(sol.handle.value, S, T, _addr(q0), _addr(human), _addr(lens), _addr(q_out), _addr(nsolve), _addr(status),
+                     None, None)
+    check(lib().gmr_retarget_group(C.cast(arr, C.c_void_p), len(jobs), int(flags), int(slices)))
+    return outs
+
+
+def retarget_group_dev(jobs, flags: int = 0, stream=None):
+    """``gmr_retarget_group_dev``: ``jobs`` = list of ``(solver, S, T, d_q0, d_human, d_len, d_q_out, d_nsolve, d_status)``
+    with device pointers (DeviceBuffer or raw); asynchronous on ``stream``."""
+    arr = (Job * max(len(jobs), 1))()
+    for i, (sol, S, T, d_q0, d_h, d_len, d_qo, d_ns, d_st) in enumerate(jobs):
+        arr[i] = Job(sol.handle.value, int(S), int(T), _addr(d_q0), _addr(d_h), _addr(d_len), _addr(d_qo), _addr(d_ns),
+                     _addr(d_st), None, None)
+    check(lib().gmr_retarget_group_dev(C.cast(arr, C.c_void_p), len(jobs), int(flags), _s(stream)))
 
 
 class Stream:

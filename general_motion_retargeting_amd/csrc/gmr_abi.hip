@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -28,6 +29,13 @@ extern "C" hipError_t gmr_ik_set_max_smem(int nvp, int nw, int tree_small, int b
 extern "C" hipError_t gmr_launch_ik_wide(const char*, const gmr::WideLayout*, const gmr::IkParams*, int, int, const double*,
                                          const double*, const int32_t*, int, double*, int32_t*, int32_t*, double*, double*,
                                          hipStream_t, unsigned long long*, void*);
+struct gmr_wide_job_desc {       // (gmr_ik_wide.hip)
+  const char* d_image; const gmr::WideLayout* L; const gmr::IkParams* P;
+  int S, T;
+  const double* d_q0; const double* d_human; const int32_t* d_len;
+  double* d_q_out; int32_t* d_nsolve; int32_t* d_status; double* d_tgt_out; double* d_err_out;
+};
+extern "C" hipError_t gmr_launch_ik_wide_group(const gmr_wide_job_desc*, int, int, hipStream_t, unsigned long long*, void*);
 extern "C" void* gmr_ik_wide_pool_create();
 extern "C" void gmr_ik_wide_pool_destroy(void*);
 extern "C" void gmr_ik_wide_pool_set_chunk(void*, int);
@@ -76,6 +84,11 @@ struct gmr_solver {
   size_t ws_bytes = 0;
   char* pin = nullptr;           // pinned host staging for small calls (one H2D + one D2H per call)
   static constexpr size_t kPinBytes = 1u << 20;
+  // the sliced host pipeline (gmr_retarget_group): HIP streams and one device workspace per slice in flight
+  static constexpr int kPipe = 4;
+  hipStream_t pipe_stream[kPipe] = {nullptr, nullptr, nullptr, nullptr};
+  char* pipe_ws[kPipe] = {nullptr, nullptr, nullptr, nullptr};
+  size_t pipe_bytes[kPipe] = {0, 0, 0, 0};
 };
 
 struct gmr_fk {
@@ -115,6 +128,18 @@ int gmr_malloc(void** ptr, size_t bytes) {
   return GMR_OK;
 }
 int gmr_free(void* ptr) { if (ptr) HIP_TRY(hipFree(ptr)); return GMR_OK; }
+int gmr_host_alloc(void** ptr, size_t bytes) {
+  if (!ptr) return fail(GMR_ERR_ARG, "gmr_host_alloc: null out pointer");
+  HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 8, hipHostMallocDefault));
+  return GMR_OK;
+}
+int gmr_host_free(void* ptr) { if (ptr) HIP_TRY(hipHostFree(ptr)); return GMR_OK; }
+int gmr_host_register(void* ptr, size_t bytes) {
+  if (!ptr) return fail(GMR_ERR_ARG, "gmr_host_register: null pointer");
+  HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return GMR_OK;
+}
+int gmr_host_unregister(void* ptr) { if (ptr) HIP_TRY(hipHostUnregister(ptr)); return GMR_OK; }
 int gmr_memset(void* ptr, int value, size_t bytes, void* stream) {
   HIP_TRY(hipMemsetAsync(ptr, value, bytes, (hipStream_t)stream));
   return GMR_OK;
@@ -260,6 +285,10 @@ int gmr_solver_destroy(gmr_solver_t* s) {
   gmr_ik_wide_pool_destroy(s->wide_pool);
   if (s->ws) (void)hipFree(s->ws);
   if (s->pin) (void)hipHostFree(s->pin);
+  for (int i = 0; i < gmr_solver::kPipe; i++) {
+    if (s->pipe_stream[i]) { (void)hipStreamSynchronize(s->pipe_stream[i]); (void)hipStreamDestroy(s->pipe_stream[i]); }
+    if (s->pipe_ws[i]) (void)hipFree(s->pipe_ws[i]);
+  }
   delete s;
   return GMR_OK;
 }
@@ -309,6 +338,161 @@ int gmr_retarget_streams_dev(gmr_solver_t* s, int S, int T, const double* d_q0, 
   return GMR_OK;
 }
 
+
+// ---- group launches: several (robot, task set) jobs as one scheduling domain ---------------------------------------
+static bool job_takes_wide_shape(const gmr_solver* s, long long total_streams) {
+  const bool helpers = s->layout4.tree_ok && (s->force_waves ? s->force_waves == 4 : total_streams <= GMR_HELPER_MAX_STREAMS);
+  return !helpers && s->wide.ok;
+}
+
+int gmr_retarget_group_dev(const gmr_job_t* jobs, int njobs, int flags, void* stream) {
+  if (njobs < 0 || (njobs > 0 && !jobs)) return fail(GMR_ERR_ARG, "bad job list");
+  long long total = 0;
+  for (int j = 0; j < njobs; j++) {
+    const gmr_job_t& J = jobs[j];
+    if (!J.solver) return fail(GMR_ERR_ARG, "job %d: null solver", j);
+    if (J.S < 0 || J.T < 0) return fail(GMR_ERR_ARG, "job %d: negative S/T", j);
+    if (J.S == 0 || J.T == 0) continue;
+    if (!J.q0 || !J.human || !J.q_out || !J.nsolve || !J.status) return fail(GMR_ERR_ARG, "job %d: null device buffer", j);
+    total += J.S;
+  }
+  // The throughput kernel is one instance for every robot of its size class: all jobs that take that shape at this
+  // width (the width of the GROUP decides, not a job's own) go out as launches of up to 8 jobs; the others -- robots
+  // that do not decompose, solvers forced to the latency shape, groups too small for the throughput shape -- one by one.
+  gmr_wide_job_desc wd[8];
+  int nw = 0;
+  void* pool = nullptr;
+  auto flush = [&]() -> int {
+    if (nw == 0) return GMR_OK;
+    hipError_t e = gmr_launch_ik_wide_group(wd, nw, flags, (hipStream_t)stream, nullptr, pool);
+    nw = 0;
+    if (e != hipSuccess) return fail(GMR_ERR_HIP, "group launch: %s", hipGetErrorString(e));
+    return GMR_OK;
+  };
+  for (int j = 0; j < njobs; j++) {
+    const gmr_job_t& J = jobs[j];
+    if (J.S == 0 || J.T == 0) continue;
+    gmr_solver* s = J.solver;
+    if (njobs > 1 && job_takes_wide_shape(s, total)) {
+      if (nw == 0) pool = s->wide_pool;
+      wd[nw++] = gmr_wide_job_desc{s->d_wide, &s->wide, &s->params, J.S, J.T, J.q0, J.human, J.len, J.q_out, J.nsolve, J.status,
+                                   J.tgt_out, J.err_out};
+      if (nw == 8) { int rc = flush(); if (rc) return rc; }
+    } else {
+      int rc = gmr_retarget_streams_dev(s, J.S, J.T, J.q0, J.human, J.len, flags, J.q_out, J.nsolve, J.status, J.tgt_out,
+                                        J.err_out, stream);
+      if (rc) return rc;
+    }
+  }
+  return flush();
+}
+
+// Host buffers, sliced and overlapped: slice k holds the streams [S_j k / n, S_j (k + 1) / n) of every job; its H2D
+// copies, its (group) launch and its D2H copies go to HIP stream k mod 4 in that order, so the copies of one slice run
+// under the kernels of its neighbours.  Slices are cut only while every slice still has a few thousand streams: a
+// launch narrower than the resident width is bound by its longest stream, and slices that share a HIP stream would
+// run those one after the other.  Pinned host memory (gmr_host_alloc / gmr_host_register) makes the copies truly
+// asynchronous; pageable memory works, staged by the runtime.
+int gmr_retarget_group(const gmr_job_t* jobs, int njobs, int flags, int slices) {
+  if (njobs < 0 || (njobs > 0 && !jobs)) return fail(GMR_ERR_ARG, "bad job list");
+  long long total = 0;
+  size_t in_bytes = 0;
+  gmr_solver* owner = nullptr;
+  for (int j = 0; j < njobs; j++) {
+    const gmr_job_t& J = jobs[j];
+    if (!J.solver) return fail(GMR_ERR_ARG, "job %d: null solver", j);
+    if (J.S < 0 || J.T < 0) return fail(GMR_ERR_ARG, "job %d: negative S/T", j);
+    if (J.S == 0 || J.T == 0) continue;
+    if (!J.q0 || !J.human || !J.q_out || !J.nsolve || !J.status) return fail(GMR_ERR_ARG, "job %d: null host buffer", j);
+    if (!owner) owner = J.solver;
+    total += J.S;
+    in_bytes += (size_t)J.S * J.T * J.solver->ts.nhuman * 56;
+  }
+  if (!owner) return GMR_OK;
+  const long long min_slice_streams = 4096;          // twice the resident width of an MI355X (8 wavefronts x 256 CUs)
+  int n;
+  if (slices > 0) n = (int)std::min<long long>(slices, total);                                   // the caller's choice
+  else n = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(16, (long long)(in_bytes >> 26)),   // ~64 MB of input per slice
+                                                            total / min_slice_streams));
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  int rc = GMR_OK;
+  hipError_t e = hipSuccess;
+  const int nslot = std::min(n, (int)gmr_solver::kPipe);
+  for (int i = 0; i < nslot; i++)
+    if (!owner->pipe_stream[i]) HIP_TRY(hipStreamCreateWithFlags(&owner->pipe_stream[i], hipStreamNonBlocking));
+  std::vector<gmr_job_t> dj((size_t)njobs);
+  for (int k = 0; k < n && rc == GMR_OK; k++) {
+    const int slot = k % gmr_solver::kPipe;
+    hipStream_t st = owner->pipe_stream[slot];
+    // layout of this slice in the slot's workspace
+    size_t need = 0;
+    struct Off { size_t q0, h, len, qo, ns, st, tg, er; int s0, S; };
+    std::vector<Off> off((size_t)njobs);
+    for (int j = 0; j < njobs; j++) {
+      const gmr_job_t& J = jobs[j];
+      Off& o = off[j];
+      o.s0 = (int)((long long)J.S * k / n);
+      o.S = (int)((long long)J.S * (k + 1) / n) - o.s0;
+      if (J.S == 0 || J.T == 0) { o.S = 0; continue; }
+      const size_t nq = J.solver->model.nq, nh = J.solver->ts.nhuman, S = (size_t)o.S, T = (size_t)J.T;
+      o.q0 = need; need += up(S * nq * 8);
+      o.h = need; need += up(S * T * nh * 56);
+      o.len = need; need += up(S * 4);
+      o.qo = need; need += up(S * T * nq * 8);
+      o.ns = need; need += up(S * T * 8);
+      o.st = need; need += up(S * 4);
+      o.tg = need; need += J.tgt_out ? up(S * T * nh * 56) : 0;
+      o.er = need; need += J.err_out ? up(S * T * 16) : 0;
+    }
+    if (need > owner->pipe_bytes[slot]) {
+      HIP_TRY(hipStreamSynchronize(st));
+      if (owner->pipe_ws[slot]) (void)hipFree(owner->pipe_ws[slot]);
+      owner->pipe_ws[slot] = nullptr; owner->pipe_bytes[slot] = 0;
+      HIP_TRY(hipMalloc((void**)&owner->pipe_ws[slot], need));
+      owner->pipe_bytes[slot] = need;
+    }
+    char* d = owner->pipe_ws[slot];
+    for (int j = 0; j < njobs && rc == GMR_OK; j++) {
+      const gmr_job_t& J = jobs[j];
+      const Off& o = off[j];
+      gmr_job_t& D = dj[j];
+      D = J;
+      D.S = o.S;
+      if (o.S == 0) continue;
+      const size_t nq = J.solver->model.nq, nh = J.solver->ts.nhuman, S = (size_t)o.S, T = (size_t)J.T, s0 = (size_t)o.s0;
+      if ((e = hipMemcpyAsync(d + o.q0, J.q0 + s0 * nq, S * nq * 8, hipMemcpyHostToDevice, st)) != hipSuccess ||
+          (e = hipMemcpyAsync(d + o.h, J.human + s0 * T * nh * 7, S * T * nh * 56, hipMemcpyHostToDevice, st)) != hipSuccess ||
+          (J.len && (e = hipMemcpyAsync(d + o.len, J.len + s0, S * 4, hipMemcpyHostToDevice, st)) != hipSuccess))
+        rc = fail(GMR_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
+      // rows the kernel does not write come back as zeros (see gmr_hip.h)
+      if (rc == GMR_OK && (J.len || J.tgt_out || J.err_out)) {
+        const size_t end = J.err_out ? o.er + up(S * T * 16) : (J.tgt_out ? o.tg + up(S * T * nh * 56) : o.st + up(S * 4));
+        if ((e = hipMemsetAsync(d + o.qo, 0, end - o.qo, st)) != hipSuccess) rc = fail(GMR_ERR_HIP, "memset: %s", hipGetErrorString(e));
+      }
+      D.q0 = (const double*)(d + o.q0); D.human = (const double*)(d + o.h); D.len = J.len ? (const int32_t*)(d + o.len) : nullptr;
+      D.q_out = (double*)(d + o.qo); D.nsolve = (int32_t*)(d + o.ns); D.status = (int32_t*)(d + o.st);
+      D.tgt_out = J.tgt_out ? (double*)(d + o.tg) : nullptr; D.err_out = J.err_out ? (double*)(d + o.er) : nullptr;
+    }
+    if (rc == GMR_OK) rc = gmr_retarget_group_dev(dj.data(), njobs, flags, st);
+    for (int j = 0; j < njobs && rc == GMR_OK; j++) {
+      const gmr_job_t& J = jobs[j];
+      const Off& o = off[j];
+      if (o.S == 0) continue;
+      const size_t nq = J.solver->model.nq, nh = J.solver->ts.nhuman, S = (size_t)o.S, T = (size_t)J.T, s0 = (size_t)o.s0;
+      if ((e = hipMemcpyAsync(J.q_out + s0 * T * nq, d + o.qo, S * T * nq * 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+          (e = hipMemcpyAsync(J.nsolve + s0 * T * 2, d + o.ns, S * T * 8, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+          (e = hipMemcpyAsync(J.status + s0, d + o.st, S * 4, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+          (J.tgt_out && (e = hipMemcpyAsync(J.tgt_out + s0 * T * nh * 7, d + o.tg, S * T * nh * 56, hipMemcpyDeviceToHost, st)) != hipSuccess) ||
+          (J.err_out && (e = hipMemcpyAsync(J.err_out + s0 * T * 2, d + o.er, S * T * 16, hipMemcpyDeviceToHost, st)) != hipSuccess))
+        rc = fail(GMR_ERR_HIP, "D2H copy: %s", hipGetErrorString(e));
+    }
+  }
+  for (int i = 0; i < nslot; i++)
+    if ((e = hipStreamSynchronize(owner->pipe_stream[i])) != hipSuccess && rc == GMR_OK)
+      rc = fail(GMR_ERR_HIP, "kernel / copies: %s", hipGetErrorString(e));
+  return rc;
+}
+
 #ifdef GMR_IK_PROFILE
 // diagnostic builds only (tools/phase_profile.py): per-stream phase cycle counters
 int gmr_retarget_streams_prof(gmr_solver_t* s, int S, int T, const double* d_q0, const double* d_human, int flags,
@@ -334,6 +518,10 @@ int gmr_retarget_streams(gmr_solver_t* s, int S, int T, const double* q0, const 
   const size_t b_q0 = (size_t)S * nq * 8, b_h = (size_t)S * T * nh * 7 * 8, b_qo = (size_t)S * T * nq * 8;
   const size_t b_ns = (size_t)S * T * 2 * 4, b_st = (size_t)S * 4, b_len = (size_t)S * 4;
   const size_t b_tg = tgt_out ? b_h : 0, b_er = err_out ? (size_t)S * T * 2 * 8 : 0;
+  if (b_h >= ((size_t)32 << 20)) {       // large batches: sliced, copies overlapped with the kernels (gmr_retarget_group)
+    const gmr_job_t job{s, S, T, q0, human, len, q_out, nsolve, status, tgt_out, err_out};
+    return gmr_retarget_group(&job, 1, flags, 0);
+  }
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   size_t o_q0 = 0, o_h = o_q0 + up(b_q0), o_len = o_h + up(b_h), o_qo = o_len + up(b_len), o_ns = o_qo + up(b_qo),
          o_st = o_ns + up(b_ns), o_tg = o_st + up(b_st), o_er = o_tg + up(b_tg), total = o_er + up(b_er);

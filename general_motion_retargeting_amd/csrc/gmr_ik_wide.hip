@@ -725,67 +725,82 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return ((unsigned long long)hi << 32) | lo;
 }
+
+// What one launch retargets for ONE (robot, task set): everything the kernel body reads that is not in the image.  A
+// plain launch passes one job by value (kernel arguments).  A GROUP launch (several robots in one scheduling domain:
+// BASELINE.json configs[3], "one kernel with per-stream model index") keeps a table of jobs in
+// device memory; streams are numbered globally (job j owns [first_j, first_j + S_j)), and a wavefront that takes an
+// item loads its job -- lane l reads dword l, the fields are taken out with v_readlane, i.e. they are scalars exactly
+// like kernel arguments.  Every wide-shape robot runs the SAME kernel instance (the layout constants WD_* are one
+// class), so nothing else has to change per item.
+struct WideJob {
+  const char* img;
+  const double* q0;
+  const double* human;
+  const int32_t* len;
+  double* q_out;
+  int32_t* nsolve;
+  int32_t* status;
+  double* tgt_out;
+  double* err_out;
+  WideDims D;
+  int max_iter, human_root, use0, use1, S, T, first;
+};
+static_assert(sizeof(WideJob) <= 256 && sizeof(WideJob) % 4 == 0, "a job is read as one dword per lane");
+constexpr int WD_MAX_JOBS = 8;
+struct WideJobTable { WideJob job[WD_MAX_JOBS]; int njobs, total; };
+
 struct WideQueue {
-  unsigned* hdr;                 // [0] head (tickets), [1] tail (pushes, starts at S), [2] nchunk
+  unsigned* hdr;                 // [0] head (tickets), [1] tail (pushes, starts at the number of streams), [2] nchunk
   unsigned* ring;
   WideStreamState* state;
   int chunk;
 };
 
-__global__ void wide_queue_init(WideQueue Q, const int32_t* __restrict__ len, int S, int T, unsigned nring) {
+// job of global stream g (MULTI launches): lane l holds first_l, the job is the last one whose first stream is <= g
+__device__ __forceinline__ int job_of(const WideJob* __restrict__ jobs, int njobs, int g, int lane) {
+  const int first = lane < njobs ? jobs[lane].first : 0x7fffffff;
+  return __popcll(__ballot(g >= first)) - 1;
+}
+
+// Queue workspace of a launch: per global stream its chunk count (summed into hdr[2]) and initial state, the ring's
+// first entries; for group launches also the device copy of the job table (the by-value table is indexed dynamically
+// here, i.e. from scratch: irrelevant in this one-shot kernel).  Q.ring == nullptr: only the table is copied.
+__global__ void wide_queue_init(WideJobTable tab, WideJob* __restrict__ d_jobs, WideQueue Q, unsigned nring) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d_jobs) {
+    const unsigned nd = (unsigned)tab.njobs * (unsigned)(sizeof(WideJob) / 4);
+    if (i < nd) reinterpret_cast<uint32_t*>(d_jobs)[i] = reinterpret_cast<const uint32_t*>(tab.job)[i];
+  }
+  if (!Q.ring) return;
   unsigned n = 0;
-  if (i < (unsigned)S) {
-    const int Ts = len ? min(max(len[i], 0), T) : T;
+  if (i < (unsigned)tab.total) {
+    int j = 0;
+    while (j + 1 < tab.njobs && (int)i >= tab.job[j + 1].first) j++;
+    const int T = tab.job[j].T;
+    const int32_t* len = tab.job[j].len;
+    const int Ts = len ? min(max(len[(int)i - tab.job[j].first], 0), T) : T;
     n = Ts > 0 ? (unsigned)((Ts + Q.chunk - 1) / Q.chunk) : 1u;       // an empty stream is one (empty) chunk
     Q.state[i] = WideStreamState{0ull, 0ull, 0, GMR_STATUS_OK};
   }
-  if (i < nring) Q.ring[i] = i < (unsigned)S ? i + 1u : 0u;
+  if (i < nring) Q.ring[i] = i < (unsigned)tab.total ? i + 1u : 0u;
   for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
   if ((threadIdx.x & 63) == 0 && n) atomicAdd(&Q.hdr[2], n);
-  if (i == 0) Q.hdr[1] = (unsigned)S;
+  if (i == 0) Q.hdr[1] = (unsigned)tab.total;
 }
 
-__global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(
-    const char* __restrict__ img, WideDims D, int max_iter, int human_root, int use0, int use1, int S, int T,
-    const double* __restrict__ q0, const double* __restrict__ human, const int32_t* __restrict__ len, int flags,
-    double* q_out, int32_t* __restrict__ nsolve, int32_t* __restrict__ status, double* __restrict__ tgt_out,
-    double* __restrict__ err_out, WideQueue Q, unsigned long long* __restrict__ prof_out) {
-  extern __shared__ __align__(16) double sm[];
-  const int lane = threadIdx.x;
-  const bool queued = Q.ring != nullptr;
-  if (!queued && (int)blockIdx.x >= S) return;
-  Prof pr;
-#ifdef GMR_IK_PROFILE
-  for (int i = 0; i < PH_COUNT; i++) pr.acc[i] = 0;
-  const unsigned long long k_t0 = __builtin_amdgcn_s_memtime(), k_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
+// One item: frames [t0, t1) of local stream s (global id g) of one job.  The job's fields arrive as parameters so that
+// the pointers keep their no-alias guarantees after inlining, whichever way the caller obtained them.
+__device__ __forceinline__ void wide_item(const char* __restrict__ img, const WideDims& D, const int max_iter, const int human_root,
+                                          const int use0, const int use1, const int T, const double* __restrict__ q0,
+                                          const double* __restrict__ human, const int32_t* __restrict__ len, const int flags,
+                                          double* q_out, int32_t* __restrict__ nsolve, int32_t* __restrict__ status,
+                                          double* __restrict__ tgt_out, double* __restrict__ err_out, const WideQueue& Q,
+                                          const bool queued, const int s, const int g, const int t0, RowState bounds, int stat,
+                                          double* sm, const int lane, Prof& pr) {
   const int nq = D.nq, nhum = D.nhum;
   const double* prm = img_at<double>(img, IM.prm);   // damping, lm_damping, tol, limit_gain, ground_offset, dt
-  const unsigned nchunk = queued ? Q.hdr[2] : 0u;
   const size_t fstride = (size_t)nhum * 7;
-  for (;;) {
-  int s = blockIdx.x, t0 = 0, stat = GMR_STATUS_OK;
-  RowState bounds = {0ull, 0ull};
-  if (queued) {
-    unsigned ticket = 0;
-    if (lane == 0) ticket = __hip_atomic_fetch_add(&Q.hdr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
-    if (ticket >= nchunk) break;
-    unsigned v = 0;
-    for (;;) {
-      if (lane == 0) v = __hip_atomic_load(&Q.ring[ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      v = __builtin_amdgcn_readfirstlane(v);
-      if (v) break;
-      __builtin_amdgcn_s_sleep(64);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the producer's q_out row and state are visible from here
-    s = (int)v - 1;
-    const WideStreamState st = Q.state[s];
-    bounds.lower = uniform64(st.lower); bounds.upper = uniform64(st.upper);
-    t0 = __builtin_amdgcn_readfirstlane(st.t_next);
-    stat = __builtin_amdgcn_readfirstlane(st.stat);
-  }
   // state that must start defined: the violation sets of the QP (double-buffered, cleared round by round)
   if (lane < 8) reinterpret_cast<unsigned long long*>(sm + LD.vset)[lane] = 0ull;
   {
@@ -824,7 +839,7 @@ __global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(
       double last_E = -1.0;                          // the stage's last residual norm (at the current configuration)
       for (int stage = 0; stage < 2; stage++) {
         if (!(stage == 0 ? use0 : use1) || (flags & GMR_FLAG_EVAL_ONLY)) continue;
-        const int K = D.K[stage];
+        const int K = stage ? D.K[1] : D.K[0];          // (constant indices: a by-value copy of the dims stays in registers)
         const uint32_t taskw = lane < K ? img_at<uint32_t>(img, IM.taski[stage])[lane] : 0u;
         // (same task list in both tables -- bit 1 of use1, gmr_ik_layout.h: the first stage's last evaluation is this
         //  stage's first, and its residuals and log-map terms are still in LDS for the Jl^-1 phase)
@@ -834,14 +849,14 @@ __global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(
           const double mu = jlog_wide(sm, img, stage, K, prm[1], lane, pr);
           const double diag = prm[0] + mu;
           PROF_BEGIN(pr);
-          pairs_wide(sm, img, stage, D.P[stage], lane);
+          pairs_wide(sm, img, stage, stage ? D.P[1] : D.P[0], lane);
           wsync();
           PROF_END(pr, PH_PAIRS);
           PROF_BEGIN(pr);
           cvec_wide(D, sm, img, stage, prm[3], lane);
           PROF_END(pr, PH_CVEC);
           PROF_BEGIN(pr);
-          hacc_wide(sm, img, D.items[stage], D.ntrip[stage], diag, lane);
+          hacc_wide(sm, img, stage ? D.items[1] : D.items[0], stage ? D.ntrip[1] : D.ntrip[0], diag, lane);
           wsync();
           PROF_END(pr, PH_HACC);
           PROF_COUNT(pr, PH_NSOLVE);
@@ -866,7 +881,7 @@ __global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(
       for (int stage = 0; stage < 2; stage++) {
         double E = 0.0;
         if (stage == 0 ? use0 : use1) {
-          const int K = D.K[stage];
+          const int K = stage ? D.K[1] : D.K[0];          // (constant indices: a by-value copy of the dims stays in registers)
           E = errors_wide(sm, lane < K ? img_at<uint32_t>(img, IM.taski[stage])[lane] : 0u, K, lane, pr);
         }
         if (lane == 0) err_out[2 * f + stage] = E;
@@ -878,21 +893,77 @@ __global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(
   }
   if (!queued) {
     if (lane == 0) status[s] = stat;
-    break;
+    return;
   }
   if (t1 < Ts) {
     // hand the stream back: state, then (release) its ring entry.  The q_out rows of this chunk were stored by all
     // lanes; the fence is executed by the wavefront, so it covers them.
-    if (lane == 0) Q.state[s] = WideStreamState{bounds.lower, bounds.upper, t1, stat};
+    if (lane == 0) Q.state[g] = WideStreamState{bounds.lower, bounds.upper, t1, stat};
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane == 0) {
       const unsigned slot = __hip_atomic_fetch_add(&Q.hdr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&Q.ring[slot], (unsigned)s + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&Q.ring[slot], (unsigned)g + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else if (lane == 0) {
     status[s] = stat;
   }
   wsync();
+}
+
+template <bool MULTI>
+__global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(WideJob J0, const WideJob* __restrict__ jobs,
+                                                                         int njobs, int total, int flags, WideQueue Q,
+                                                                         unsigned long long* __restrict__ prof_out) {
+  extern __shared__ __align__(16) double sm[];
+  const int lane = threadIdx.x;
+  const bool queued = Q.ring != nullptr;
+  if (!queued && (int)blockIdx.x >= (MULTI ? total : J0.S)) return;
+  Prof pr;
+#ifdef GMR_IK_PROFILE
+  for (int i = 0; i < PH_COUNT; i++) pr.acc[i] = 0;
+  const unsigned long long k_t0 = __builtin_amdgcn_s_memtime(), k_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  const unsigned nchunk = queued ? Q.hdr[2] : 0u;
+  for (;;) {
+    int g = blockIdx.x, t0 = 0, stat = GMR_STATUS_OK;
+    RowState bounds = {0ull, 0ull};
+    if (queued) {
+      unsigned ticket = 0;
+      if (lane == 0) ticket = __hip_atomic_fetch_add(&Q.hdr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ticket = __builtin_amdgcn_readfirstlane(ticket);
+      if (ticket >= nchunk) break;
+      unsigned v = 0;
+      for (;;) {
+        if (lane == 0) v = __hip_atomic_load(&Q.ring[ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = __builtin_amdgcn_readfirstlane(v);
+        if (v) break;
+        __builtin_amdgcn_s_sleep(64);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the producer's q_out row and state are visible from here
+      g = (int)v - 1;
+      const WideStreamState st = Q.state[g];
+      bounds.lower = uniform64(st.lower); bounds.upper = uniform64(st.upper);
+      t0 = __builtin_amdgcn_readfirstlane(st.t_next);
+      stat = __builtin_amdgcn_readfirstlane(st.stat);
+    }
+    if (MULTI) {
+      // the job's fields by SCALAR loads from the table, addressed as constant memory: like kernel arguments, the
+      // compiler may re-load one where it is used instead of keeping it in a register across the frame loop
+      typedef const WideJob __attribute__((address_space(4))) CJob;
+      const int j = __builtin_amdgcn_readfirstlane(job_of(jobs, njobs, g, lane));
+      CJob* cj = reinterpret_cast<CJob*>(reinterpret_cast<uintptr_t>(jobs + j));
+      WideDims D;
+      D.nb = cj->D.nb; D.nq = cj->D.nq; D.nv = cj->D.nv; D.nhum = cj->D.nhum; D.nhop = cj->D.nhop;
+      D.K[0] = cj->D.K[0]; D.K[1] = cj->D.K[1]; D.P[0] = cj->D.P[0]; D.P[1] = cj->D.P[1];
+      D.ntrip[0] = cj->D.ntrip[0]; D.ntrip[1] = cj->D.ntrip[1]; D.items[0] = cj->D.items[0]; D.items[1] = cj->D.items[1];
+      wide_item(cj->img, D, cj->max_iter, cj->human_root, cj->use0, cj->use1, cj->T, cj->q0, cj->human, cj->len, flags,
+                cj->q_out, cj->nsolve, cj->status, cj->tgt_out, cj->err_out, Q, queued, g - cj->first, g, t0, bounds, stat, sm,
+                lane, pr);
+    } else {
+      wide_item(J0.img, J0.D, J0.max_iter, J0.human_root, J0.use0, J0.use1, J0.T, J0.q0, J0.human, J0.len, flags, J0.q_out,
+                J0.nsolve, J0.status, J0.tgt_out, J0.err_out, Q, queued, g, g, t0, bounds, stat, sm, lane, pr);
+    }
+    if (!queued) break;
   }
 #ifdef GMR_IK_PROFILE
   pr.acc[PH_TICKS] = __builtin_amdgcn_s_memtime() - k_t0;
@@ -930,7 +1001,7 @@ extern "C" void* gmr_ik_wide_pool_create() {
   WidePool* p = new WidePool();
   int dev = 0, ncu = 0, nblk = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(gmr::wide::ik_wide_kernel), 64,
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(gmr::wide::ik_wide_kernel<false>), 64,
                                                    gmr::WD_LDS_BYTES) != hipSuccess)
     ncu = nblk = 0;
   p->slots = ncu * nblk;
@@ -952,61 +1023,112 @@ extern "C" void gmr_ik_wide_pool_destroy(void* pool) {
   delete p;
 }
 
+// one job of a launch as gmr_abi.hip hands it over (device pointers)
+struct gmr_wide_job_desc {
+  const char* d_image; const gmr::WideLayout* L; const gmr::IkParams* P;
+  int S, T;
+  const double* d_q0; const double* d_human; const int32_t* d_len;
+  double* d_q_out; int32_t* d_nsolve; int32_t* d_status; double* d_tgt_out; double* d_err_out;
+};
+
+// Launch njobs >= 1 jobs as ONE scheduling domain on `stream`: a single job runs the plain instance (its fields are
+// kernel arguments), several jobs the group instance (job table in the workspace).  Queued dispatch engages when the
+// streams of ALL jobs together outnumber the resident wavefronts.
+extern "C" hipError_t gmr_launch_ik_wide_group(const gmr_wide_job_desc* jd, int njobs, int flags, hipStream_t stream,
+                                               unsigned long long* d_prof, void* pool) {
+  using namespace gmr::wide;
+  if (njobs < 1 || njobs > WD_MAX_JOBS) return hipErrorInvalidValue;
+  WidePool* p = static_cast<WidePool*>(pool);
+  WideJobTable tab;
+  memset(&tab, 0, sizeof tab);
+  long long total = 0, nring = 0;
+  int chunk = 0, maxT = 0, n = 0;
+  if (p) { std::lock_guard<std::mutex> g(p->mu); chunk = p->chunk; }
+  for (int j = 0; j < njobs; j++) {
+    if (jd[j].S <= 0 || jd[j].T <= 0) continue;
+    WideJob& J = tab.job[n++];
+    J.img = jd[j].d_image; J.q0 = jd[j].d_q0; J.human = jd[j].d_human; J.len = jd[j].d_len; J.q_out = jd[j].d_q_out;
+    J.nsolve = jd[j].d_nsolve; J.status = jd[j].d_status; J.tgt_out = jd[j].d_tgt_out; J.err_out = jd[j].d_err_out;
+    J.D = static_cast<const gmr::WideDims&>(*jd[j].L);
+    J.max_iter = jd[j].P->max_iter; J.human_root = jd[j].P->human_root; J.use0 = jd[j].P->use0; J.use1 = jd[j].P->use1;
+    J.S = jd[j].S; J.T = jd[j].T; J.first = (int)total;
+    total += jd[j].S;
+    maxT = std::max(maxT, jd[j].T);
+  }
+  if (n == 0) return hipSuccess;
+  if (total > 0x7fffffffll) return hipErrorInvalidValue;
+  tab.njobs = n; tab.total = (int)total;
+  const bool multi = n > 1;
+  // the ring has one entry per chunk: very long jobs get longer chunks rather than a ring beyond 64 MB (more than 2^24
+  // streams cannot be helped by longer chunks: the loop ends at chunk >= T and the launch below is a direct one)
+  auto ring_entries = [&](int c) { long long r = 0; for (int j = 0; j < n; j++) r += (long long)tab.job[j].S * ((tab.job[j].T + c - 1) / c); return r; };
+  while (chunk > 0 && chunk < maxT && ring_entries(chunk) > (1ll << 24)) chunk *= 2;
+  // queued mode pays only when streams outnumber the resident wavefronts and have more than one chunk
+  const bool queued = p && !d_prof && chunk > 0 && p->slots > 0 && maxT > chunk && total > (long long)p->slots * p->min_streams_per_slot;
+  if (queued) nring = ring_entries(chunk);
+  WideQueue Q{nullptr, nullptr, nullptr, 0};
+  WideJob* d_jobs = nullptr;
+  int grid = (int)total;
+  if (queued || multi) {
+    if (!p) return hipErrorInvalidValue;
+    // workspace: [hdr 256 B | job table | ring | per-stream state]
+    const size_t o_jobs = 256, o_ring = 4096, o_state = o_ring + ((size_t)nring * 4 + 255) / 256 * 256;
+    static_assert(256 + sizeof(WideJob) * WD_MAX_JOBS <= 4096, "job table must fit in front of the ring");
+    const size_t bytes = o_state + (queued ? (size_t)total * sizeof(WideStreamState) : 0);
+    char* base = nullptr;
+    {
+      std::lock_guard<std::mutex> g(p->mu);
+      QueueWs& w = p->ws[stream];
+      if (w.bytes < bytes) {
+        hipError_t e = hipSuccess;
+        if (w.base) { if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e; (void)hipFree(w.base); w.base = nullptr; w.bytes = 0; }
+        if ((e = hipMalloc((void**)&w.base, bytes)) != hipSuccess) return e;
+        w.bytes = bytes;
+      }
+      base = w.base;
+    }
+    if (multi) d_jobs = reinterpret_cast<WideJob*>(base + o_jobs);
+    if (queued) {
+      Q.hdr = reinterpret_cast<unsigned*>(base);
+      Q.ring = reinterpret_cast<unsigned*>(base + o_ring);
+      Q.state = reinterpret_cast<WideStreamState*>(base + o_state);
+      Q.chunk = chunk;
+      hipError_t e = hipMemsetAsync(base, 0, 256, stream);
+      if (e != hipSuccess) return e;
+      grid = (int)std::min<long long>(total, p->slots);
+    }
+    const unsigned nthr = (unsigned)std::max<long long>(std::max<long long>(nring, queued ? total : 0), (long long)(n * sizeof(WideJob) / 4));
+    hipLaunchKernelGGL(wide_queue_init, dim3((nthr + 255) / 256), dim3(256), 0, stream, tab, d_jobs, Q, (unsigned)nring);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  if (multi)
+    hipLaunchKernelGGL(ik_wide_kernel<true>, dim3(grid), dim3(64), gmr::WD_LDS_BYTES, stream, tab.job[0], d_jobs, n, (int)total,
+                       flags, Q, d_prof);
+  else
+    hipLaunchKernelGGL(ik_wide_kernel<false>, dim3(grid), dim3(64), gmr::WD_LDS_BYTES, stream, tab.job[0], d_jobs, n, (int)total,
+                       flags, Q, d_prof);
+  return hipGetLastError();
+}
+
 extern "C" hipError_t gmr_launch_ik_wide(const char* d_image, const gmr::WideLayout* L, const gmr::IkParams* P, int S, int T,
                                          const double* d_q0, const double* d_human, const int32_t* d_len, int flags,
                                          double* d_q_out, int32_t* d_nsolve, int32_t* d_status, double* d_tgt_out,
                                          double* d_err_out, hipStream_t stream, unsigned long long* d_prof, void* pool) {
   if (S <= 0 || T <= 0) return hipSuccess;
-  WidePool* p = static_cast<WidePool*>(pool);
-  gmr::wide::WideQueue Q{nullptr, nullptr, nullptr, 0};
-  int grid = S, chunk = 0;
-  if (p) { std::lock_guard<std::mutex> g(p->mu); chunk = p->chunk; }
-  // the ring has one entry per chunk: very long jobs get longer chunks rather than a ring beyond 64 MB (more than 2^24
-  // streams cannot be helped by longer chunks: the loop ends at chunk >= T and the launch below is a direct one)
-  while (chunk > 0 && chunk < T && (long long)S * ((T + chunk - 1) / chunk) > (1ll << 24)) chunk *= 2;
-  // queued mode pays only when streams outnumber the resident wavefronts and have more than one chunk
-  if (p && !d_prof && chunk > 0 && p->slots > 0 && T > chunk && (long long)S > (long long)p->slots * p->min_streams_per_slot) {
-    const size_t nring = (size_t)S * (size_t)((T + chunk - 1) / chunk);
-    const size_t o_ring = 256, o_state = o_ring + (nring * 4 + 255) / 256 * 256;
-    const size_t total = o_state + (size_t)S * sizeof(gmr::wide::WideStreamState);
-    char* base = nullptr;
-    {
-      std::lock_guard<std::mutex> g(p->mu);
-      QueueWs& w = p->ws[stream];
-      if (w.bytes < total) {
-        hipError_t e = hipSuccess;
-        if (w.base) { if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e; (void)hipFree(w.base); w.base = nullptr; w.bytes = 0; }
-        if ((e = hipMalloc((void**)&w.base, total)) != hipSuccess) return e;
-        w.bytes = total;
-      }
-      base = w.base;
-    }
-    Q.hdr = reinterpret_cast<unsigned*>(base);
-    Q.ring = reinterpret_cast<unsigned*>(base + o_ring);
-    Q.state = reinterpret_cast<gmr::wide::WideStreamState*>(base + o_state);
-    Q.chunk = chunk;
-    hipError_t e = hipMemsetAsync(base, 0, 256, stream);
-    if (e != hipSuccess) return e;
-    const unsigned nthr = (unsigned)std::max(nring, (size_t)S);
-    hipLaunchKernelGGL(gmr::wide::wide_queue_init, dim3((nthr + 255) / 256), dim3(256), 0, stream, Q, d_len, S, T, (unsigned)nring);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    grid = std::min(S, p->slots);
-  }
-  hipLaunchKernelGGL(gmr::wide::ik_wide_kernel, dim3(grid), dim3(64), gmr::WD_LDS_BYTES, stream, d_image,
-                     static_cast<const gmr::WideDims&>(*L), P->max_iter, P->human_root, P->use0, P->use1, S, T, d_q0, d_human,
-                     d_len, flags, d_q_out, d_nsolve, d_status, d_tgt_out, d_err_out, Q, d_prof);
-  return hipGetLastError();
+  const gmr_wide_job_desc jd{d_image, L, P, S, T, d_q0, d_human, d_len, d_q_out, d_nsolve, d_status, d_tgt_out, d_err_out};
+  return gmr_launch_ik_wide_group(&jd, 1, flags, stream, d_prof, pool);
 }
 
 // the kernel's registers / LDS as the runtime sees them (occupancy reporting)
 extern "C" hipError_t gmr_ik_wide_attributes(int* num_regs, int* lds_bytes, int* max_waves_per_cu) {
   hipFuncAttributes a;
-  hipError_t e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(gmr::wide::ik_wide_kernel));
+  hipError_t e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(gmr::wide::ik_wide_kernel<false>));
   if (e != hipSuccess) return e;
   if (num_regs) *num_regs = a.numRegs;
   if (lds_bytes) *lds_bytes = gmr::WD_LDS_BYTES;
   int nblk = 0;
-  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(gmr::wide::ik_wide_kernel), 64,
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(gmr::wide::ik_wide_kernel<false>), 64,
                                                    gmr::WD_LDS_BYTES);
   if (max_waves_per_cu) *max_waves_per_cu = nblk;
   return e;

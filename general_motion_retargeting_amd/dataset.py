@@ -69,44 +69,25 @@ def retarget_clips(src_human: str, tgt_robot: str, clips: Sequence, fps: Sequenc
     return [postprocess_clip(qpos[i, : lens[i]], km, fps[i], height_adjust, root_origin_offset) for i in range(S)]
 
 
-def retarget_mixed(groups: Sequence[Dict], offset_to_ground: bool = False):
-    """Mixed-robot batch (BASELINE.json configs[3]): every group = one (source, robot, height) with
-    its own streams; the groups are launched back to back on separate HIP streams (one kernel per
-    robot model, concurrent on the device) and collected with one synchronisation per group.
+def retarget_mixed(groups: Sequence[Dict], offset_to_ground: bool = False, slices: int = 0, pinned_outputs: bool = False):
+    """Mixed-robot batch (BASELINE.json configs[3]; SURVEY.md section 8d "one kernel with per-stream model index"): every
+    group = one (source, robot, height) with its own streams; ALL groups form one scheduling domain on the device --
+    the robots of the throughput kernel's size class (every shipped one) share a resident grid and one queue of
+    (robot, stream, chunk) items (``gmr_retarget_group``) -- and the host buffers are cut into slices whose copies
+    overlap the kernels.  Bit-identical to retargeting every group by itself.
 
     ``groups[i]`` = ``{"src_human", "tgt_robot", "human": f64[S,T,nhuman,7], optional "lens",
-    "actual_human_height"}``.  Returns a list of ``(qpos[S,T,nq], nsolve[S,T,2], status[S])``.
+    "actual_human_height"}``; arrays allocated with ``_lib.pinned_empty`` are copied asynchronously.
+    Returns a list of ``(qpos[S,T,nq], nsolve[S,T,2], status[S])``.
     """
     from . import _lib
-    work = []
+    jobs, keep = [], []
     for g in groups:
         gmr = GeneralMotionRetargeting(g["src_human"], g["tgt_robot"], actual_human_height=g.get("actual_human_height"))
-        sol = gmr.hip_solver
-        human = np.ascontiguousarray(g["human"], dtype=np.float64)
-        S, T = human.shape[:2]
-        q0 = np.broadcast_to(gmr.model.qpos0, (S, gmr.model.nq)).copy()
-        st = _lib.Stream()
-        d_q0 = _lib.DeviceBuffer.from_host(q0)
-        d_h = _lib.DeviceBuffer.from_host(human)
-        lens = g.get("lens")
-        d_len = _lib.DeviceBuffer.from_host(np.ascontiguousarray(lens, dtype=np.int32)) if lens is not None else None
-        d_qo = _lib.DeviceBuffer(S * T * sol.nq * 8)
-        d_ns = _lib.DeviceBuffer(S * T * 8)
-        d_st = _lib.DeviceBuffer(S * 4)
-        if lens is not None:
-            _lib.check(_lib.lib().gmr_memset(d_qo.ptr, 0, d_qo.nbytes, None))
-            _lib.check(_lib.lib().gmr_memset(d_ns.ptr, 0, d_ns.nbytes, None))
-            _lib.check(_lib.lib().gmr_stream_sync(None))
-        work.append((gmr, sol, st, S, T, (d_q0, d_h, d_len, d_qo, d_ns, d_st)))
+        keep.append(gmr)
+        jobs.append({"solver": gmr.hip_solver, "human": g["human"], "lens": g.get("lens")})
     flags = _lib.FLAG_OFFSET_TO_GROUND if offset_to_ground else 0
-    for gmr, sol, st, S, T, (d_q0, d_h, d_len, d_qo, d_ns, d_st) in work:      # enqueue everything first
-        sol.retarget_streams_dev(S, T, d_q0, d_h, d_len, flags, d_qo, d_ns, d_st, st)
-    out = []
-    for gmr, sol, st, S, T, (d_q0, d_h, d_len, d_qo, d_ns, d_st) in work:
-        st.sync()
-        out.append((d_qo.to_host((S, T, sol.nq), np.float64), d_ns.to_host((S, T, 2), np.int32),
-                    d_st.to_host((S,), np.int32)))
-    return out
+    return _lib.retarget_group(jobs, flags, slices, out_pinned=pinned_outputs)   # (rows beyond a stream's length: zeros)
 
 
 def retarget_bvh_files(bvh_files: Sequence[str], tgt_robot: str, fps: float = 30.0, height_adjust: bool = False,

@@ -117,6 +117,39 @@ int gmr_retarget_streams_dev(gmr_solver_t* solver, int S, int T, const double* d
 int gmr_retarget_streams(gmr_solver_t* solver, int S, int T, const double* q0, const double* human,
                          const int32_t* len, int flags, double* q_out, int32_t* nsolve, int32_t* status,
                          double* tgt_out, double* err_out);
+/* ---- several (robot, task set) jobs as ONE scheduling domain -------------------------------------------------------
+ * BASELINE.json configs[3] ("all 6 robots mixed-DoF batch"; SURVEY.md section 8d: "per-robot kernels or one kernel
+ * with per-stream model index"): the reference would run one mp.Pool worker per file whatever its robot
+ * (scripts/smplx_to_robot_dataset.py:241-242).  Every robot of the throughput kernel's size class runs the same
+ * kernel instance, so the jobs of a group share one resident grid and one device-side queue of (job, stream, chunk)
+ * items: the group is balanced as a whole and its launch ends within one chunk of its last stream.  Results are
+ * bit-identical to launching every job by itself.  Jobs that do not take the throughput shape (a robot that does not
+ * decompose, a solver forced to 4 wavefronts, a group of <= 300 streams) are launched one by one on the same stream. */
+typedef struct gmr_job {
+  gmr_solver_t* solver;
+  int32_t S, T;
+  const double* q0;        /* [S][nq]              the buffers of gmr_retarget_streams, per job                     */
+  const double* human;     /* [S][T][nhuman][7]                                                                      */
+  const int32_t* len;      /* [S] or NULL                                                                            */
+  double* q_out;           /* [S][T][nq]                                                                             */
+  int32_t* nsolve;         /* [S][T][2]                                                                              */
+  int32_t* status;         /* [S]                                                                                    */
+  double* tgt_out;         /* [S][T][nhuman][7] or NULL                                                              */
+  double* err_out;         /* [S][T][2] or NULL                                                                      */
+} gmr_job_t;
+/* device pointers, asynchronous on `stream` */
+int gmr_retarget_group_dev(const gmr_job_t* jobs, int njobs, int flags, void* stream);
+/* HOST pointers: the streams are cut into `slices` slices (0 = automatic: about 64 MB of input each, never fewer than
+ * 4 096 streams per slice, at most 16; > 0: exactly that many, at most one per stream) whose H2D copies, launch and D2H copies go to one of four HIP streams, so that
+ * copy(k+1) || kernel(k) || copy-back(k-1); synchronises before returning.  Use pinned host memory (below) for the
+ * copies to be asynchronous.  gmr_retarget_streams takes this path by itself for inputs of 32 MB and more. */
+int gmr_retarget_group(const gmr_job_t* jobs, int njobs, int flags, int slices);
+/* pinned (page-locked) host memory for the host-pointer entry points; gmr_host_register pins a caller's own buffer */
+int gmr_host_alloc(void** ptr, size_t bytes);
+int gmr_host_free(void* ptr);
+int gmr_host_register(void* ptr, size_t bytes);
+int gmr_host_unregister(void* ptr);
+
 /* LDS bytes per stream of the IK kernel for this solver (occupancy reporting). */
 int gmr_retarget_lds_bytes(const gmr_solver_t* solver);
 

@@ -761,3 +761,84 @@ def test_fk_split_walk_is_bit_equal_to_one_wavefront_per_block(hip, monkeypatch)
             assert np.array_equal(bp, bp1) and np.array_equal(br, br1) and mz == mz1, (robot, waves)
             bp_only, none, _ = fkn.fk(rp, rq, dof, want_rot=False)
             assert none is None and np.array_equal(bp_only, bp1), (robot, waves)
+
+
+SIX_ROBOTS = ["unitree_g1", "booster_t1", "stanford_toddy", "fourier_n1", "engineai_pm01", "hightorque_hi"]
+
+
+def _six_robot_batch(hip, counts, T, seed, ragged=True, fail=None):
+    """One job per robot of BASELINE.json configs[3] with `counts[i]` streams (tiled from 16 distinct motions)."""
+    from general_motion_retargeting_amd import synth
+    rng = np.random.default_rng(seed)
+    jobs, setups = [], []
+    for i, (robot, S) in enumerate(zip(SIX_ROBOTS, counts)):
+        su = get_setup("smplx", robot)
+        bh, bq = synth.make_streams(su.model, su.tt, 16, T, seed=seed + 100 * i)
+        pick = rng.integers(0, 16, size=S)
+        human, q0 = bh[pick].copy(), bq[pick].copy()
+        lens = rng.integers(0, T + 1, size=S).astype(np.int32) if ragged else None
+        if ragged:
+            lens[:4] = [T, 0, 1, T]
+        if fail is not None and i == fail[0]:
+            human[fail[1], fail[2], 0, 3:] = np.nan
+            if ragged:
+                lens[fail[1]] = T
+        sol = hip.Solver(su.mb, su.ts)
+        jobs.append({"solver": sol, "human": human, "q0": q0, "lens": lens})
+        setups.append(su)
+    return jobs, setups
+
+
+@pytest.mark.gpu
+def test_group_launch_is_one_scheduling_domain_and_bit_identical(hip, oracle):
+    """BASELINE.json configs[3]: all six robots in ONE launch -- one resident grid, one device-side queue of (robot,
+    stream, chunk) items ("one kernel with per-stream model index").  Ragged lengths, empty streams, a
+    failing stream; the bits are those of every robot launched by itself, one workgroup per stream; a sample against the
+    oracle.  Both the queued group (streams outnumber the resident wavefronts) and the direct one."""
+    for counts, T in (([500, 430, 390, 410, 380, 450], 6), ([90, 70, 60, 80, 50, 65], 5)):
+        jobs, setups = _six_robot_batch(hip, counts, T, seed=77, fail=(2, 7, 2))
+        ref = []
+        for j in jobs:
+            j["solver"].set_waves(1)
+            j["solver"].set_dispatch(0)
+            ref.append(j["solver"].retarget_streams(j["q0"], j["human"], lens=j["lens"]))
+            j["solver"].set_dispatch(2)
+        assert ref[2][2][7] == hip.STATUS_QP_FAILED and sum(int((r[2] != 0).sum()) for r in ref) == 1
+        for slices in (1, 2):
+            out = hip.retarget_group(jobs, 0, slices)
+            for r, (a, o) in enumerate(zip(ref, out)):
+                for x, y in zip(a, o):
+                    assert np.array_equal(x, y, equal_nan=True), (counts[0], slices, SIX_ROBOTS[r])
+        for r, (su, j) in enumerate(zip(setups, jobs)):
+            for s in (0, 3, counts[r] - 1):
+                n = int(j["lens"][s])
+                if n == 0 or (r == 2 and s == 7):
+                    continue
+                q_o, ns_o, _ = oracle.retarget_streams(su.mb, su.ts, j["q0"][s:s + 1], j["human"][s:s + 1, :n])
+                assert np.array_equal(out[r][1][s, :n], ns_o[0]) and np.abs(out[r][0][s, :n] - q_o[0]).max() <= TOL_RAD
+                assert not out[r][0][s, n:].any()                 # rows beyond a stream's length come back as zeros
+
+
+@pytest.mark.gpu
+def test_group_launch_device_pointers_and_pinned_pipeline(hip):
+    """The device-pointer group entry on a caller's stream, and the sliced host pipeline through pinned buffers, against the
+    plain per-solver call."""
+    jobs, _ = _six_robot_batch(hip, [1500, 1400, 1450, 1380, 1420, 1490], 4, seed=5, ragged=False)    # 8 640 streams: 2 slices
+    ref = [j["solver"].retarget_streams(j["q0"], j["human"]) for j in jobs]
+    pj = [{"solver": j["solver"], "human": hip.pinned_copy(j["human"]), "q0": hip.pinned_copy(j["q0"])} for j in jobs]
+    out = hip.retarget_group(pj, 0, 0, out_pinned=True)
+    for a, o in zip(ref, out):
+        assert all(np.array_equal(x, y) for x, y in zip(a, o))
+    st = hip.Stream()
+    dev, bufs = [], []
+    for j in jobs:
+        sol, (S, T) = j["solver"], j["human"].shape[:2]
+        b = (hip.DeviceBuffer.from_host(j["q0"]), hip.DeviceBuffer.from_host(j["human"]), hip.DeviceBuffer(S * T * sol.nq * 8),
+             hip.DeviceBuffer(S * T * 8), hip.DeviceBuffer(S * 4))
+        bufs.append(b)
+        dev.append((sol, S, T, b[0], b[1], None, b[2], b[3], b[4]))
+    hip.retarget_group_dev(dev, 0, st)
+    st.sync()
+    for (sol, S, T, *_), b, a in zip(dev, bufs, ref):
+        assert np.array_equal(b[2].to_host((S, T, sol.nq), np.float64), a[0])
+        assert np.array_equal(b[3].to_host((S, T, 2), np.int32), a[1]) and not b[4].to_host((S,), np.int32).any()
