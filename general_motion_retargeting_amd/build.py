@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgmrhip.so")
 OBJ = os.path.join(os.path.dirname(HERE), "build", "obj")
 SOURCES = ["gmr_ik.hip", "gmr_ik_wide.hip", "gmr_fk.hip", "gmr_smplx.hip", "gmr_comm.hip", "gmr_abi.hip"]
-HEADERS = ["gmr_device_math.h", "gmr_ik_layout.h", "gmr_ik_wide_layout.h", "gmr_ik_prof.h", "gmr_ik_tree.h",
+HEADERS = ["gmr_ik_wide_item.inc", "gmr_device_math.h", "gmr_ik_layout.h", "gmr_ik_wide_layout.h", "gmr_ik_prof.h", "gmr_ik_tree.h",
            "gmr_fk_tree.h", "gmr_internal.h", "../../include/gmr_hip.h", "../../include/gmr_types.h"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 # The throughput kernel must stay within 256 registers (two wavefronts per SIMD).  Machine-LICM hoists every FP64

@@ -54,7 +54,8 @@ __device__ __forceinline__ double bpermute_d(int addr, double v) {
 // ---------------------------------------------------------------------------------------------
 // FK: mj_kinematics semantics (App. A.3) by pointer jumping, lane = body (see fk_wave in gmr_ik.hip)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fk_wide(const WideDims& D, double* sm, const char* __restrict__ img, int lane, Prof& pr,
+template <class DimsRef>
+__device__ __forceinline__ void fk_wide(DimsRef D, double* sm, const char* __restrict__ img, int lane, Prof& pr,
                                         bool root_is_unit = false) {
   PROF_BEGIN(pr);
   const int nb = D.nb;
@@ -215,7 +216,8 @@ __device__ __forceinline__ void pairs_wide(double* sm, const char* __restrict__ 
 }
 
 // (c) lane = dof: gather c; bounds of the limited hinges (mink ConfigurationLimit)
-__device__ __forceinline__ void cvec_wide(const WideDims& D, double* sm, const char* __restrict__ img, int stage,
+template <class DimsRef>
+__device__ __forceinline__ void cvec_wide(DimsRef D, double* sm, const char* __restrict__ img, int stage,
                                           double limit_gain, int lane) {
   const double* cpart = sm + LD.cpart;
   if (lane < D.nv) {
@@ -310,7 +312,8 @@ __device__ __forceinline__ void hacc_wide(double* sm, const char* __restrict__ i
 // ---------------------------------------------------------------------------------------------
 struct RowState { unsigned long long lower, upper; };
 
-__device__ __forceinline__ int solve_rows(const WideDims& D, double* sm, const char* __restrict__ img, int lane_in,
+template <class DimsRef>
+__device__ __forceinline__ int solve_rows(DimsRef D, double* sm, const char* __restrict__ img, int lane_in,
                                           RowState& bs, Prof& pr) {
   constexpr int NL = WD_NL, NT = WD_NT, NV = NL + NT, TLD = WD_LD;
   static_assert(NV == 16, "a limb's local matrix fills one 16-lane row");
@@ -622,7 +625,8 @@ __device__ __forceinline__ int solve_rows(const WideDims& D, double* sm, const c
 }
 
 // (sin, cos) of every hinge's half angle for a configuration that did not come out of integrate_wide (q0)
-__device__ __forceinline__ void hinge_sincos(const WideDims& D, double* sm, int lane) {
+template <class DimsRef>
+__device__ __forceinline__ void hinge_sincos(DimsRef D, double* sm, int lane) {
   if (lane >= 6 && lane < D.nv) {
     double s, c;
     sincos_small(0.5 * (sm + LD.q)[7 + lane - 6], &s, &c);
@@ -632,7 +636,8 @@ __device__ __forceinline__ void hinge_sincos(const WideDims& D, double* sm, int 
 }
 
 // mj_integratePos with v = dq/dt (App. A.7): lane 0 the free joint, lane 6+h hinge h (see integrate_wave)
-__device__ __forceinline__ void integrate_wide(const WideDims& D, double* sm, double dt, int lane, Prof& pr) {
+template <class DimsRef>
+__device__ __forceinline__ void integrate_wide(DimsRef D, double* sm, double dt, int lane, Prof& pr) {
   PROF_BEGIN(pr);
   double* q = sm + LD.q;
   const double* dq = sm + LD.x;
@@ -664,7 +669,8 @@ __device__ __forceinline__ void integrate_wide(const WideDims& D, double* sm, do
 }
 
 // target preprocessing (motion_retarget.py:203-270); lane = human body
-__device__ __forceinline__ void preprocess_wide(const WideDims& D, double* sm, const char* __restrict__ img, int human_root,
+template <class DimsRef>
+__device__ __forceinline__ void preprocess_wide(DimsRef D, double* sm, const char* __restrict__ img, int human_root,
                                                 double ground_offset, int flags, int lane, Prof& pr) {
   PROF_BEGIN(pr);
   const double* raw = sm + LD.raw;
@@ -789,181 +795,78 @@ __global__ void wide_queue_init(WideJobTable tab, WideJob* __restrict__ d_jobs, 
   if (i == 0) Q.hdr[1] = (unsigned)tab.total;
 }
 
-// One item: frames [t0, t1) of local stream s (global id g) of one job.  The job's fields arrive as parameters so that
-// the pointers keep their no-alias guarantees after inlining, whichever way the caller obtained them.
-__device__ __forceinline__ void wide_item(const char* __restrict__ img, const WideDims& D, const int max_iter, const int human_root,
-                                          const int use0, const int use1, const int T, const double* __restrict__ q0,
-                                          const double* __restrict__ human, const int32_t* __restrict__ len, const int flags,
-                                          double* q_out, int32_t* __restrict__ nsolve, int32_t* __restrict__ status,
-                                          double* __restrict__ tgt_out, double* __restrict__ err_out, const WideQueue& Q,
-                                          const bool queued, const int s, const int g, const int t0, RowState bounds, int stat,
-                                          double* sm, const int lane, Prof& pr) {
-  const int nq = D.nq, nhum = D.nhum;
-  const double* prm = img_at<double>(img, IM.prm);   // damping, lm_damping, tol, limit_gain, ground_offset, dt
-  const size_t fstride = (size_t)nhum * 7;
-  // state that must start defined: the violation sets of the QP (double-buffered, cleared round by round)
-  if (lane < 8) reinterpret_cast<unsigned long long*>(sm + LD.vset)[lane] = 0ull;
-  {
-    const double* qs = t0 == 0 ? q0 + (size_t)s * nq : q_out + ((size_t)s * T + t0 - 1) * nq;
-    for (int i = lane; i < nq; i += 64) (sm + LD.q)[i] = qs[i];
+// next item of the queue: false when the tickets are used up (the wavefront ends)
+__device__ __forceinline__ bool queue_pop(const WideQueue& Q, const unsigned nchunk, const int lane, int& g, int& t0, int& stat,
+                                          RowState& bounds) {
+  unsigned ticket = 0;
+  if (lane == 0) ticket = __hip_atomic_fetch_add(&Q.hdr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  if (ticket >= nchunk) return false;
+  unsigned v = 0;
+  for (;;) {
+    if (lane == 0) v = __hip_atomic_load(&Q.ring[ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v = __builtin_amdgcn_readfirstlane(v);
+    if (v) break;
+    __builtin_amdgcn_s_sleep(64);
   }
-  wsync();
-  hinge_sincos(D, sm, lane);
-  wsync();
-  fk_wide(D, sm, img, lane, pr, t0 > 0);
-
-  const int Ts = len ? min(len[s], T) : T;
-  const int t1 = queued ? min(t0 + Q.chunk, Ts) : Ts;
-  const double* hs = human + (size_t)s * T * fstride;
-  double r0 = 0.0, r1 = 0.0;
-  if (t0 < t1) {
-    const double* nx = hs + (size_t)t0 * fstride;
-    if (lane < (int)fstride) r0 = nx[lane];
-    if (lane + 64 < (int)fstride) r1 = nx[lane + 64];
-  }
-  for (int t = t0; t < t1; t++) {
-    if (lane < (int)fstride) (sm + LD.raw)[lane] = r0;
-    if (lane + 64 < (int)fstride) (sm + LD.raw)[lane + 64] = r1;
-    if (t + 1 < t1) {                                  // prefetch the next frame (nhuman * 7 <= 112 doubles)
-      const double* nx = hs + (size_t)(t + 1) * fstride;
-      if (lane < (int)fstride) r0 = nx[lane];
-      if (lane + 64 < (int)fstride) r1 = nx[lane + 64];
-    }
-    wsync();
-    int ns0 = 0, ns1 = 0;
-    const size_t f = (size_t)s * T + t;
-    if (stat == GMR_STATUS_OK) {
-      preprocess_wide(D, sm, img, human_root, prm[4], flags, lane, pr);
-      if (tgt_out)     // the poses handed to task.set_target (motion_retarget.py:117-136) = scaled_human_data
-        for (int i = lane; i < (int)fstride; i += 64) tgt_out[f * fstride + i] = (sm + LD.tgt)[i];
-      double last_E = -1.0;                          // the stage's last residual norm (at the current configuration)
-      for (int stage = 0; stage < 2; stage++) {
-        if (!(stage == 0 ? use0 : use1) || (flags & GMR_FLAG_EVAL_ONLY)) continue;
-        const int K = stage ? D.K[1] : D.K[0];          // (constant indices: a by-value copy of the dims stays in registers)
-        const uint32_t taskw = lane < K ? img_at<uint32_t>(img, IM.taski[stage])[lane] : 0u;
-        // (same task list in both tables -- bit 1 of use1, gmr_ik_layout.h: the first stage's last evaluation is this
-        //  stage's first, and its residuals and log-map terms are still in LDS for the Jl^-1 phase)
-        double curr = (stage == 1 && (use1 & 2) && last_E >= 0.0) ? last_E : errors_wide(sm, taskw, K, lane, pr);
-        int nsol = 0, num_iter = 0;
-        for (;;) {
-          const double mu = jlog_wide(sm, img, stage, K, prm[1], lane, pr);
-          const double diag = prm[0] + mu;
-          PROF_BEGIN(pr);
-          pairs_wide(sm, img, stage, stage ? D.P[1] : D.P[0], lane);
-          wsync();
-          PROF_END(pr, PH_PAIRS);
-          PROF_BEGIN(pr);
-          cvec_wide(D, sm, img, stage, prm[3], lane);
-          PROF_END(pr, PH_CVEC);
-          PROF_BEGIN(pr);
-          hacc_wide(sm, img, stage ? D.items[1] : D.items[0], stage ? D.ntrip[1] : D.ntrip[0], diag, lane);
-          wsync();
-          PROF_END(pr, PH_HACC);
-          PROF_COUNT(pr, PH_NSOLVE);
-          PROF_COUNT(pr, PH_NFACT);
-          const int rc = solve_rows(D, sm, img, lane, bounds, pr);
-          if (rc != GMR_STATUS_OK) { stat = rc; break; }
-          integrate_wide(D, sm, prm[5], lane, pr);
-          fk_wide(D, sm, img, lane, pr);
-          const double next = errors_wide(sm, taskw, K, lane, pr);
-          last_E = next;
-          nsol++;
-          if (nsol > 1) num_iter++;
-          if (!(curr - next > prm[2] && num_iter < max_iter)) break;
-          curr = next;
-        }
-        if (stage == 0) ns0 = nsol; else ns1 = nsol;
-        if (stat != GMR_STATUS_OK) break;
-      }
-    }
-    if (err_out && stat == GMR_STATUS_OK) {
-      // error1() / error2() of the reference (motion_retarget.py:188-200) at the configuration this frame ends with
-      for (int stage = 0; stage < 2; stage++) {
-        double E = 0.0;
-        if (stage == 0 ? use0 : use1) {
-          const int K = stage ? D.K[1] : D.K[0];          // (constant indices: a by-value copy of the dims stays in registers)
-          E = errors_wide(sm, lane < K ? img_at<uint32_t>(img, IM.taski[stage])[lane] : 0u, K, lane, pr);
-        }
-        if (lane == 0) err_out[2 * f + stage] = E;
-      }
-    }
-    for (int i = lane; i < nq; i += 64) q_out[f * nq + i] = (sm + LD.q)[i];
-    if (lane == 0) { nsolve[2 * f] = ns0; nsolve[2 * f + 1] = ns1; }
-    wsync();
-  }
-  if (!queued) {
-    if (lane == 0) status[s] = stat;
-    return;
-  }
-  if (t1 < Ts) {
-    // hand the stream back: state, then (release) its ring entry.  The q_out rows of this chunk were stored by all
-    // lanes; the fence is executed by the wavefront, so it covers them.
-    if (lane == 0) Q.state[g] = WideStreamState{bounds.lower, bounds.upper, t1, stat};
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if (lane == 0) {
-      const unsigned slot = __hip_atomic_fetch_add(&Q.hdr[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&Q.ring[slot], (unsigned)g + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  } else if (lane == 0) {
-    status[s] = stat;
-  }
-  wsync();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the producer's q_out row and state are visible from here
+  g = (int)v - 1;
+  const WideStreamState st = Q.state[g];
+  bounds.lower = uniform64(st.lower); bounds.upper = uniform64(st.upper);
+  t0 = __builtin_amdgcn_readfirstlane(st.t_next);
+  stat = __builtin_amdgcn_readfirstlane(st.stat);
+  return true;
 }
 
-template <bool MULTI>
-__global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(WideJob J0, const WideJob* __restrict__ jobs,
-                                                                         int njobs, int total, int flags, WideQueue Q,
-                                                                         unsigned long long* __restrict__ prof_out) {
+// Plain launch: ONE job, its fields are individual kernel arguments.  That matters: with ~100 SGPRs for ~350
+// wave-uniform values the compiler re-loads a kernel ARGUMENT where it is used (s_load from the kernarg segment: no VALU
+// slot), while a value it cannot re-load is parked in a VGPR lane and comes back through v_readlane.  Passing the job as
+// one by-value struct (or reading it through a pointer to the kernarg segment) loses that property: measured, +500
+// v_readlane instructions in the code object and -4 % frames/s.
+__global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(
+    const char* __restrict__ img, WideDims D, int max_iter, int human_root, int use0, int use1, int S, int T,
+    const double* __restrict__ q0, const double* __restrict__ human, const int32_t* __restrict__ len, int flags,
+    double* q_out, int32_t* __restrict__ nsolve, int32_t* __restrict__ status, double* __restrict__ tgt_out,
+    double* __restrict__ err_out, WideQueue Q, unsigned long long* __restrict__ prof_out) {
   extern __shared__ __align__(16) double sm[];
   const int lane = threadIdx.x;
   const bool queued = Q.ring != nullptr;
-  if (!queued && (int)blockIdx.x >= (MULTI ? total : J0.S)) return;
+  if (!queued && (int)blockIdx.x >= S) return;
   Prof pr;
 #ifdef GMR_IK_PROFILE
   for (int i = 0; i < PH_COUNT; i++) pr.acc[i] = 0;
   const unsigned long long k_t0 = __builtin_amdgcn_s_memtime(), k_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+  const int nq = D.nq, nhum = D.nhum;
+  const double* prm = img_at<double>(img, IM.prm);   // damping, lm_damping, tol, limit_gain, ground_offset, dt
   const unsigned nchunk = queued ? Q.hdr[2] : 0u;
+  const size_t fstride = (size_t)nhum * 7;
   for (;;) {
-    int g = blockIdx.x, t0 = 0, stat = GMR_STATUS_OK;
-    RowState bounds = {0ull, 0ull};
-    if (queued) {
-      unsigned ticket = 0;
-      if (lane == 0) ticket = __hip_atomic_fetch_add(&Q.hdr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ticket = __builtin_amdgcn_readfirstlane(ticket);
-      if (ticket >= nchunk) break;
-      unsigned v = 0;
-      for (;;) {
-        if (lane == 0) v = __hip_atomic_load(&Q.ring[ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v = __builtin_amdgcn_readfirstlane(v);
-        if (v) break;
-        __builtin_amdgcn_s_sleep(64);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the producer's q_out row and state are visible from here
-      g = (int)v - 1;
-      const WideStreamState st = Q.state[g];
-      bounds.lower = uniform64(st.lower); bounds.upper = uniform64(st.upper);
-      t0 = __builtin_amdgcn_readfirstlane(st.t_next);
-      stat = __builtin_amdgcn_readfirstlane(st.stat);
+  int s = blockIdx.x, t0 = 0, stat = GMR_STATUS_OK;
+  RowState bounds = {0ull, 0ull};
+  if (queued) {
+    unsigned ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(&Q.hdr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket >= nchunk) break;
+    unsigned v = 0;
+    for (;;) {
+      if (lane == 0) v = __hip_atomic_load(&Q.ring[ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = __builtin_amdgcn_readfirstlane(v);
+      if (v) break;
+      __builtin_amdgcn_s_sleep(64);
     }
-    if (MULTI) {
-      // the job's fields by SCALAR loads from the table, addressed as constant memory: like kernel arguments, the
-      // compiler may re-load one where it is used instead of keeping it in a register across the frame loop
-      typedef const WideJob __attribute__((address_space(4))) CJob;
-      const int j = __builtin_amdgcn_readfirstlane(job_of(jobs, njobs, g, lane));
-      CJob* cj = reinterpret_cast<CJob*>(reinterpret_cast<uintptr_t>(jobs + j));
-      WideDims D;
-      D.nb = cj->D.nb; D.nq = cj->D.nq; D.nv = cj->D.nv; D.nhum = cj->D.nhum; D.nhop = cj->D.nhop;
-      D.K[0] = cj->D.K[0]; D.K[1] = cj->D.K[1]; D.P[0] = cj->D.P[0]; D.P[1] = cj->D.P[1];
-      D.ntrip[0] = cj->D.ntrip[0]; D.ntrip[1] = cj->D.ntrip[1]; D.items[0] = cj->D.items[0]; D.items[1] = cj->D.items[1];
-      wide_item(cj->img, D, cj->max_iter, cj->human_root, cj->use0, cj->use1, cj->T, cj->q0, cj->human, cj->len, flags,
-                cj->q_out, cj->nsolve, cj->status, cj->tgt_out, cj->err_out, Q, queued, g - cj->first, g, t0, bounds, stat, sm,
-                lane, pr);
-    } else {
-      wide_item(J0.img, J0.D, J0.max_iter, J0.human_root, J0.use0, J0.use1, J0.T, J0.q0, J0.human, J0.len, flags, J0.q_out,
-                J0.nsolve, J0.status, J0.tgt_out, J0.err_out, Q, queued, g, g, t0, bounds, stat, sm, lane, pr);
-    }
-    if (!queued) break;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the producer's q_out row and state are visible from here
+    s = (int)v - 1;
+    const WideStreamState st = Q.state[s];
+    bounds.lower = uniform64(st.lower); bounds.upper = uniform64(st.upper);
+    t0 = __builtin_amdgcn_readfirstlane(st.t_next);
+    stat = __builtin_amdgcn_readfirstlane(st.stat);
+  }
+  const int gs = s;
+#define GMR_DIMS_T const WideDims&
+#include "gmr_ik_wide_item.inc"
+#undef GMR_DIMS_T
   }
 #ifdef GMR_IK_PROFILE
   pr.acc[PH_TICKS] = __builtin_amdgcn_s_memtime() - k_t0;
@@ -973,6 +876,48 @@ __global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(WideJob
 #else
   (void)prof_out;
 #endif
+}
+
+// Group launch: the job of an item comes from the table in device memory, by scalar loads through a constant-memory
+// pointer (wave-uniform, like kernel arguments, but not re-loadable for free: this instance keeps a few more values in
+// registers than the plain one).
+__global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_group_kernel(const WideJob* __restrict__ jobs, int njobs,
+                                                                               int total, int flags, WideQueue Q) {
+  extern __shared__ __align__(16) double sm[];
+  const int lane = threadIdx.x;
+  const bool queued = Q.ring != nullptr;
+  if (!queued && (int)blockIdx.x >= total) return;
+  Prof pr;
+#ifdef GMR_IK_PROFILE
+  for (int i = 0; i < PH_COUNT; i++) pr.acc[i] = 0;
+#endif
+  const unsigned nchunk = queued ? Q.hdr[2] : 0u;
+  for (;;) {
+  int gs = blockIdx.x, t0 = 0, stat = GMR_STATUS_OK;
+  RowState bounds = {0ull, 0ull};
+  if (queued && !queue_pop(Q, nchunk, lane, gs, t0, stat, bounds)) break;
+  typedef const WideJob __attribute__((address_space(4))) CJob;
+  const int j = __builtin_amdgcn_readfirstlane(job_of(jobs, njobs, gs, lane));
+  CJob* cj = reinterpret_cast<CJob*>(reinterpret_cast<uintptr_t>(jobs + j));
+  const WideDims __attribute__((address_space(4)))& D = cj->D;
+  const char* __restrict__ img = cj->img;
+  const int max_iter = cj->max_iter, human_root = cj->human_root, use0 = cj->use0, use1 = cj->use1, T = cj->T;
+  const double* __restrict__ q0 = cj->q0;
+  const double* __restrict__ human = cj->human;
+  const int32_t* __restrict__ len = cj->len;
+  double* q_out = cj->q_out;
+  int32_t* __restrict__ nsolve = cj->nsolve;
+  int32_t* __restrict__ status = cj->status;
+  double* __restrict__ tgt_out = cj->tgt_out;
+  double* __restrict__ err_out = cj->err_out;
+  const int s = gs - cj->first;
+  const int nq = D.nq, nhum = D.nhum;
+  const double* prm = img_at<double>(img, IM.prm);
+  const size_t fstride = (size_t)nhum * 7;
+#define GMR_DIMS_T const WideDims __attribute__((address_space(4)))&
+#include "gmr_ik_wide_item.inc"
+#undef GMR_DIMS_T
+  }
 }
 
 }  // namespace wide
@@ -1001,7 +946,7 @@ extern "C" void* gmr_ik_wide_pool_create() {
   WidePool* p = new WidePool();
   int dev = 0, ncu = 0, nblk = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(gmr::wide::ik_wide_kernel<false>), 64,
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(gmr::wide::ik_wide_kernel), 64,
                                                    gmr::WD_LDS_BYTES) != hipSuccess)
     ncu = nblk = 0;
   p->slots = ncu * nblk;
@@ -1102,12 +1047,14 @@ extern "C" hipError_t gmr_launch_ik_wide_group(const gmr_wide_job_desc* jd, int 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  if (multi)
-    hipLaunchKernelGGL(ik_wide_kernel<true>, dim3(grid), dim3(64), gmr::WD_LDS_BYTES, stream, tab.job[0], d_jobs, n, (int)total,
-                       flags, Q, d_prof);
-  else
-    hipLaunchKernelGGL(ik_wide_kernel<false>, dim3(grid), dim3(64), gmr::WD_LDS_BYTES, stream, tab.job[0], d_jobs, n, (int)total,
-                       flags, Q, d_prof);
+  if (multi) {
+    hipLaunchKernelGGL(ik_wide_group_kernel, dim3(grid), dim3(64), gmr::WD_LDS_BYTES, stream, d_jobs, n, (int)total, flags, Q);
+  } else {
+    const WideJob& J = tab.job[0];
+    hipLaunchKernelGGL(ik_wide_kernel, dim3(grid), dim3(64), gmr::WD_LDS_BYTES, stream, J.img, J.D, J.max_iter, J.human_root,
+                       J.use0, J.use1, J.S, J.T, J.q0, J.human, J.len, flags, J.q_out, J.nsolve, J.status, J.tgt_out, J.err_out, Q,
+                       d_prof);
+  }
   return hipGetLastError();
 }
 
@@ -1123,12 +1070,12 @@ extern "C" hipError_t gmr_launch_ik_wide(const char* d_image, const gmr::WideLay
 // the kernel's registers / LDS as the runtime sees them (occupancy reporting)
 extern "C" hipError_t gmr_ik_wide_attributes(int* num_regs, int* lds_bytes, int* max_waves_per_cu) {
   hipFuncAttributes a;
-  hipError_t e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(gmr::wide::ik_wide_kernel<false>));
+  hipError_t e = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(gmr::wide::ik_wide_kernel));
   if (e != hipSuccess) return e;
   if (num_regs) *num_regs = a.numRegs;
   if (lds_bytes) *lds_bytes = gmr::WD_LDS_BYTES;
   int nblk = 0;
-  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(gmr::wide::ik_wide_kernel<false>), 64,
+  e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(gmr::wide::ik_wide_kernel), 64,
                                                    gmr::WD_LDS_BYTES);
   if (max_waves_per_cu) *max_waves_per_cu = nblk;
   return e;
