@@ -200,6 +200,160 @@ class Shard:
             b.free()
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Extra legs of the N = 1 line: the other BASELINE.json configs and the end-to-end (PCIe-
+# inclusive) rates in the driver-run record.  Each leg carries its own `workload` string; a leg that fails reports
+# {"error": ...} and never touches the headline fields.  Run after every timed region of the headline.
+# ---------------------------------------------------------------------------------------------------------------------
+def _wall(fn, reps):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return ts
+
+
+def leg_e2e(solver, q0, human, q_all, h_all, steps):
+    """configs[1] and the 1M-frame batch THROUGH HOST BUFFERS (SURVEY.md 8d timing protocol: "wall-clock end-to-end
+    incl. H2D/D2H ... report both"): pageable NumPy arrays, and pinned arrays with the copies of a slice running under
+    the kernels of its neighbours (gmr_retarget_group)."""
+    out = {}
+
+    def both(tag, q, h, reps, workload):
+        frames = h.shape[0] * h.shape[1]
+        jp = [{"solver": solver, "human": h, "q0": q}]
+        ts_page = _wall(lambda: _lib.retarget_group(jp, 0, 0), reps + 1)[1:]
+        jpin = [{"solver": solver, "human": _lib.pinned_copy(h), "q0": _lib.pinned_copy(q)}]
+        outs = _lib.group_outputs(jpin)          # page-locked once: locking 300 MB costs more than retargeting 1M frames
+        ts_pin = _wall(lambda: _lib.retarget_group(jpin, 0, 0, outs=outs), reps + 1)[1:]
+        ts_pin1 = _wall(lambda: _lib.retarget_group(jpin, 0, 1, outs=outs), reps + 1)[1:]
+        out[tag] = {"workload": workload, "unit": "frames/s", "steps": reps,
+                    "pinned_overlapped": frames / float(np.mean(ts_pin)), "pinned_one_slice": frames / float(np.mean(ts_pin1)),
+                    "pageable": frames / float(np.mean(ts_page)),
+                    "ms_per_step": {"pinned_overlapped": float(np.mean(ts_pin)) * 1e3, "pinned_one_slice": float(np.mean(ts_pin1)) * 1e3,
+                                    "pageable": float(np.mean(ts_page)) * 1e3},
+                    "bytes_per_step": {"h2d": int(h.nbytes + q.nbytes), "d2h": int(frames * (solver.nq * 8 + 8) + h.shape[0] * 4)}}
+
+    both("configs1", q0, human, max(2, min(steps, 10)),
+         f"configs[1] S={human.shape[0]} x T={human.shape[1]} through host buffers: H2D + kernel + D2H per step, wall clock")
+    if h_all is not None:
+        both("strong_1m", q_all, h_all, 2,
+             f"the 1M-frame batch S={h_all.shape[0]} x T={h_all.shape[1]} through host buffers, wall clock; `pinned_overlapped` = "
+             f"sliced automatically (about 64 MB of input per slice on four HIP streams)")
+    return out
+
+
+def leg_config2(seed=30):
+    """BASELINE.json configs[2] on this one GPU: LAFAN1-shaped stand-in (no BVH files offline; SURVEY.md 8d "Config 3")."""
+    from general_motion_retargeting_amd import GeneralMotionRetargeting
+    rng = np.random.default_rng(3)
+    lens = rng.integers(3000, 9500, size=77)
+    lens = (lens * (496000 / lens.sum())).astype(np.int32)
+    g = GeneralMotionRetargeting("bvh", "unitree_g1", actual_human_height=1.75)
+    T = int(lens.max())
+    base_h, _ = synth.make_streams(g.model, g._tables, 77, 1200, seed=seed, workers=4)   # 1200-frame motifs, played back and forth
+    idx = np.arange(T) % 2398
+    idx = np.where(idx < 1200, idx, 2398 - idx)
+    human = np.ascontiguousarray(base_h[:, idx])
+    frames = int(lens.sum())
+    sol = g.hip_solver
+    S, nq = 77, sol.nq
+    q0 = np.broadcast_to(g.model.qpos0, (S, nq)).copy()
+    d = [_lib.DeviceBuffer.from_host(q0), _lib.DeviceBuffer.from_host(human), _lib.DeviceBuffer.from_host(lens),
+         _lib.DeviceBuffer(S * T * nq * 8), _lib.DeviceBuffer(S * T * 8), _lib.DeviceBuffer(S * 4)]
+    ms = []
+    for i in range(2):
+        a, b = _lib.Event(), _lib.Event()
+        a.record(None)
+        sol.retarget_streams_dev(S, T, d[0], d[1], d[2], 0, d[3], d[4], d[5], None)
+        b.record(None)
+        ms.append(a.elapsed_ms(b))
+    st = d[5].to_host((S,), np.int32)
+    ns = d[4].to_host((S, T, 2), np.int32)
+    for x in d:
+        x.free()
+    t0 = time.perf_counter()
+    q, ns2, st2 = g.retarget_streams(human, lens=lens)
+    wall = time.perf_counter() - t0
+    shards = sharding.lpt_partition(lens.tolist(), 8)
+    return {"workload": f"BASELINE.json configs[2] stand-in: 77 ragged streams (LAFAN1's shape, bvh -> Unitree G1), {frames} frames, "
+                        f"longest clip {T}, ONE launch on one GPU (latency shape: 77 < 256 CUs)",
+            "unit": "frames/s", "value": frames / (min(ms) * 1e-3), "ms_per_step": float(min(ms)), "steps": 2,
+            "pcie_inclusive_pageable": frames / wall, "failed_streams": int((st != 0).sum() + (st2 != 0).sum()),
+            "mean_solves_per_frame": float(ns.sum()) / frames,
+            "lpt_8gpu_frames_per_rank": [int(lens[s_].sum()) for s_ in shards],
+            "lpt_8gpu_longest_clip_per_rank": [int(lens[s_].max()) for s_ in shards],
+            "note": "the makespan is the longest clip x per-frame latency: sharding 77 streams over 8 GPUs cannot shorten it"}
+
+
+SIX_ROBOTS = ["unitree_g1", "booster_t1", "stanford_toddy", "fourier_n1", "engineai_pm01", "hightorque_hi"]
+
+
+def leg_config3(S_total=4096, T=256, motifs=128, seed=1):
+    """BASELINE.json configs[3] on this one GPU: 1M frames round-robin over six robots as ONE scheduling domain."""
+    from general_motion_retargeting_amd import GeneralMotionRetargeting
+    jobs, keep = [], []
+    for r, robot in enumerate(SIX_ROBOTS):
+        gm = GeneralMotionRetargeting("smplx", robot)
+        S = len(range(r, S_total, len(SIX_ROBOTS)))
+        bh, _ = synth.make_streams(gm.model, gm._tables, min(motifs, S), T, seed=seed + 1000 * r, workers=4)
+        human = _lib.pinned_empty((S, T, bh.shape[2], 7))
+        for s0 in range(0, S, len(bh)):
+            human[s0:s0 + len(bh)] = bh[: S - s0]
+        q0 = _lib.pinned_copy(np.broadcast_to(gm.model.qpos0, (S, gm.model.nq)))
+        keep.append(gm)
+        jobs.append({"solver": gm.hip_solver, "human": human, "q0": q0})
+    nfr = sum(j["human"].shape[0] for j in jobs) * T
+    dev, bufs = [], []
+    for j in jobs:
+        sol, S = j["solver"], j["human"].shape[0]
+        b = (_lib.DeviceBuffer.from_host(j["q0"]), _lib.DeviceBuffer.from_host(j["human"]), _lib.DeviceBuffer(S * T * sol.nq * 8),
+             _lib.DeviceBuffer(S * T * 8), _lib.DeviceBuffer(S * 4))
+        bufs.append(b)
+        dev.append((sol, S, T, b[0], b[1], None, b[2], b[3], b[4]))
+    ms = []
+    for i in range(3):
+        a, b = _lib.Event(), _lib.Event()
+        a.record(None)
+        _lib.retarget_group_dev(dev, 0, None)
+        b.record(None)
+        ms.append(a.elapsed_ms(b))
+    failed = sum(int((b[4].to_host((S,), np.int32) != 0).sum()) for (_, S, *_), b in zip(dev, bufs))
+    spf = [float(b[3].to_host((S, T, 2), np.int32).sum()) / (S * T) for (_, S, *_), b in zip(dev, bufs)]
+    for b in bufs:
+        for x in b:
+            x.free()
+    outs = _lib.group_outputs(jobs)
+    ts = _wall(lambda: _lib.retarget_group(jobs, 0, 0, outs=outs), 3)[1:]
+    return {"workload": f"BASELINE.json configs[3] on ONE GPU: {nfr} frames = {S_total} streams x {T} frames round-robin over "
+                        f"{', '.join(SIX_ROBOTS)} (smplx configs), one group launch = one resident grid + one device-side queue",
+            "unit": "frames/s", "value": nfr / (min(ms[1:]) * 1e-3), "ms_per_step": float(min(ms[1:])), "steps": 2,
+            "pcie_inclusive_pinned": nfr / float(np.mean(ts)), "failed_streams": failed, "mean_solves_per_frame": spf}
+
+
+def leg_config4_hip(nframes=300, warm=30, hz=120.0):
+    """BASELINE.json configs[4]: one stream, 51-body frames delivered one at a time at 120 Hz, retarget(dict) per frame."""
+    from general_motion_retargeting_amd import GeneralMotionRetargeting
+    g = GeneralMotionRetargeting("fbx", "unitree_g1", actual_human_height=1.6)
+    human, q0 = synth.make_streams(g.model, g._tables, 1, nframes, seed=3)
+    frames = synth.streams_to_dicts(g._tables, human[0])
+    lat = []
+    t_next = time.perf_counter()
+    for t in range(nframes):
+        while time.perf_counter() < t_next:
+            pass
+        t_next += 1.0 / hz
+        a = time.perf_counter()
+        g.retarget(frames[t])
+        lat.append(time.perf_counter() - a)
+    lat = np.array(lat[warm:]) * 1e3
+    return ({"workload": f"BASELINE.json configs[4]: fbx -> Unitree G1, one stream, {nframes - warm} frames paced at {hz:.0f} Hz, "
+                         f"one retarget(dict) call per frame (1 H2D + 1 launch + 1 D2H)",
+             "unit": "ms per frame", "p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)),
+             "max_ms": float(lat.max())}, (g, human, q0, nframes, warm, hz))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,6 +368,7 @@ def main():
     ap.add_argument("--src", default="smplx")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="N = 1: skip the e2e / configs[2..4] legs")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -412,6 +567,34 @@ def main():
                     "roofline": roofline,
                 },
             })
+        # ---- the other configs and the end-to-end rates (N = 1 only; after every timed region of the headline) ------------
+        leg4_ctx = None
+        if world == 1 and comm.backend == "none" and standin is None and not args.no_extra_legs:
+            if sres is not None:
+                for k_ in ("mine", "all"):
+                    if k_ in keep:
+                        keep[k_].free()
+            legs = {}
+
+            def run_leg(name, fn):
+                t_leg = time.perf_counter()
+                try:
+                    legs[name] = fn()
+                except Exception as e:  # noqa: BLE001 -- an extra leg must never cost the headline
+                    legs[name] = {"error": f"{type(e).__name__}: {e}"}
+                if isinstance(legs[name], dict):
+                    legs[name]["leg_seconds"] = round(time.perf_counter() - t_leg, 2)
+
+            run_leg("e2e", lambda: leg_e2e(solver, q0, human, q_all if strong else None, h_all if strong else None, args.steps))
+            run_leg("config2_lafan1_shape", leg_config2)
+            run_leg("config3_mixed_1m", leg_config3)
+
+            def _leg4():
+                nonlocal leg4_ctx
+                res, leg4_ctx = leg_config4_hip()
+                return res
+            run_leg("config4_latency", _leg4)
+            out["legs"] = legs
         if standin is not None:
             out["standin"] = os.environ["GMR_BENCH_STANDIN"]
             out["data"] = "synthetic (STAND-IN compute function: rehearsal of the launcher / N > 1 protocol, not a measurement)"
@@ -443,6 +626,23 @@ def main():
                         "tolerance, the QP here is solved exactly) was measured: 0 of 67 344 frames change their solve count "
                         "under a DAQP-like termination rule, max joint deviation 5.8e-7 rad (profiles/r02_parity_risk.json)",
             }
+            if leg4_ctx is not None:       # configs[4] on the CPU: the same paced frames, one oracle call per frame, one thread
+                g4, h4, q04, n4, w4, hz4 = leg4_ctx
+                state = q04[0].copy()
+                lat = []
+                t_next = time.perf_counter()
+                for t in range(n4):
+                    while time.perf_counter() < t_next:
+                        pass
+                    t_next += 1.0 / hz4
+                    a4 = time.perf_counter()
+                    qq, _, _ = orc.retarget_streams(g4._model_blob, g4._taskset_blob, state[None], h4[:, t:t + 1], nthreads=1)
+                    state = qq[0, 0]
+                    lat.append(time.perf_counter() - a4)
+                lat = np.array(lat[w4:]) * 1e3
+                out["cpu_baseline"]["config4_latency"] = {"p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)),
+                                                          "max_ms": float(lat.max()), "threads": 1,
+                                                          "sample": f"the {n4 - w4} paced frames of legs.config4_latency, one oracle call per frame"}
             out["max_joint_err_rad"] = float(np.abs(q_hip[..., 7:] - q_cpu[..., 7:]).max())
             out["max_root_pos_err_m"] = float(np.abs(q_hip[..., :3] - q_cpu[..., :3]).max())
             out["frames_with_different_solve_count"] = int((ns_hip != ns_cpu).any(axis=-1).sum())

@@ -257,14 +257,26 @@ def _addr(x):
     return x.value if isinstance(x, C.c_void_p) else int(x)
 
 
-def retarget_group(jobs, flags: int = 0, slices: int = 0, out_pinned: bool = False):
+def group_outputs(jobs, pinned: bool = True):
+    """Output arrays ``(q_out, nsolve, status)`` per job for :func:`retarget_group` (``outs=``): page-locking memory costs
+    far more than retargeting a batch does, so a caller that runs many batches allocates them once."""
+    empty = pinned_empty if pinned else (lambda shape, dtype: np.empty(shape, dtype))
+    outs = []
+    for j in jobs:
+        sol, (S, T) = j["solver"], j["human"].shape[:2]
+        outs.append((empty((S, T, sol.nq), np.float64), empty((S, T, 2), np.int32), empty((S,), np.int32)))
+    return outs
+
+
+def retarget_group(jobs, flags: int = 0, slices: int = 0, out_pinned: bool = False, outs=None):
     """Several (solver, batch) jobs as ONE scheduling domain through host buffers (``gmr_retarget_group``): the mixed-robot
     batch of BASELINE.json configs[3].  ``jobs`` = list of dicts ``{"solver": Solver, "human": f64[S,T,nhuman,7], optional
     "q0": f64[S,nq] (default the solver's qpos0), "lens": i32[S]}``.  Returns one ``(q_out, nsolve, status)`` per job.
-    Inputs in pinned memory (:func:`pinned_empty`) and ``out_pinned=True`` make the copies asynchronous, so that they
-    overlap the kernels slice by slice."""
+    Inputs in pinned memory (:func:`pinned_empty`) and pinned outputs (``outs=`` from :func:`group_outputs`, reused across
+    calls; or ``out_pinned=True``: allocated per call, which is slow) make the copies asynchronous, so that they overlap the
+    kernels slice by slice."""
     arr = (Job * max(len(jobs), 1))()
-    keep, outs = [], []
+    keep, given, outs = [], outs, []
     empty = pinned_empty if out_pinned else (lambda shape, dtype: np.empty(shape, dtype))
     for i, j in enumerate(jobs):
         sol = j["solver"]
@@ -285,9 +297,15 @@ def retarget_group(jobs, flags: int = 0, slices: int = 0, out_pinned: bool = Fal
             lens = np.ascontiguousarray(lens, dtype=np.int32)
             if lens.shape != (S,):
                 raise ValueError(f"job {i}: lens must be [S]")
-        q_out = empty((S, T, sol.nq), np.float64)
-        nsolve = empty((S, T, 2), np.int32)
-        status = np.zeros(S, dtype=np.int32)
+        if given is not None:
+            q_out, nsolve, status = given[i]
+            if q_out.shape != (S, T, sol.nq) or nsolve.shape != (S, T, 2) or status.shape != (S,) or q_out.dtype != np.float64 \
+                    or nsolve.dtype != np.int32 or status.dtype != np.int32 or not (q_out.flags.c_contiguous and nsolve.flags.c_contiguous):
+                raise ValueError(f"job {i}: outs do not match the batch")
+        else:
+            q_out = empty((S, T, sol.nq), np.float64)
+            nsolve = empty((S, T, 2), np.int32)
+            status = np.zeros(S, dtype=np.int32)
         keep.append((human, q0, lens))
         outs.append((q_out, nsolve, status))
         arr[i] = Job(sol.handle.value, S, T, _addr(q0), _addr(human), _addr(lens), _addr(q_out), _addr(nsolve), _addr(status),

@@ -115,9 +115,10 @@ def measure_mixed(S_total=4096, T=256, reps=3):
                                   ("host_pinned_auto", pj, True, 0)):
         res = None
         ts = []
+        outs = _lib.group_outputs(jj, pinned=pin)
         for _ in range(reps + 1):
             t0 = time.perf_counter()
-            res = _lib.retarget_group(jj, 0, slices, out_pinned=pin)
+            res = _lib.retarget_group(jj, 0, slices, outs=outs)
             ts.append(time.perf_counter() - t0)
         ok = all(np.array_equal(a[0], r[0]) and np.array_equal(a[1], r[1]) for a, r in zip(res, ref))
         out[name] = {"seconds": ts[1:], "frames_per_s": nfr / min(ts[1:]), "bit_identical": bool(ok)}
