@@ -68,92 +68,13 @@ F_ERR = {"unitree_g1": 2.1e3}
 METRIC = "retargeted frames/sec (whole node) + max joint-angle err vs CPU ref, G1 29-DoF"
 
 
-def _free_ports(n):
-    import socket
-    socks, ports = [], []
-    for _ in range(n):
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        socks.append(s)
-        ports.append(s.getsockname()[1])
-    for s in socks:
-        s.close()
-    return ports
-
-
 def self_launch(n: int, argv) -> int:
     """`python bench.py --gpus N` without an external launcher: this process starts N rank processes of this script
     and does nothing else -- in particular it never loads libgmrhip.so and never initialises a GPU.  Rank 0's stdout
-    (the ONE JSON line) is relayed; the first non-zero exit of any rank ends the job with that code (the remaining
-    ranks are terminated by PID)."""
-    import signal
-    import subprocess
-    port, comm_port = _free_ports(2)
-    timeout = float(os.environ.get("GMR_BENCH_TIMEOUT", "1500"))
-    procs = []
-    for r in range(n):
-        env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), GMR_COMM_PORT=str(comm_port), GMR_BENCH_SELF_LAUNCHED="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
-        env.setdefault("GMR_COMM_TIMEOUT", "120")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, start_new_session=True))
-
-    def stop_all():
-        for p in procs:
-            if p.poll() is None:
-                try:
-                    os.killpg(p.pid, signal.SIGTERM)        # each rank is its own session: its generator workers go with it
-                except OSError:
-                    pass
-        t_kill = time.time() + 5.0
-        for p in procs:
-            try:
-                p.wait(max(0.1, t_kill - time.time()))
-            except subprocess.TimeoutExpired:
-                try:
-                    os.killpg(p.pid, signal.SIGKILL)
-                except OSError:
-                    pass
-
-    import threading
-    lines = []
-
-    def relay():
-        for raw in procs[0].stdout:
-            line = raw.decode(errors="replace")
-            lines.append(line)
-            sys.stdout.write(line)
-            sys.stdout.flush()
-
-    th = threading.Thread(target=relay, daemon=True)
-    th.start()
-    t_end = time.time() + timeout
-    rc = 0
-    try:
-        while True:
-            codes = [p.poll() for p in procs]
-            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
-            if bad:
-                r, c = bad[0]
-                print(f"[bench launcher] rank {r} exited with code {c}: stopping the other ranks", file=sys.stderr, flush=True)
-                rc = c if c > 0 else 1
-                break
-            if all(c == 0 for c in codes):
-                break
-            if time.time() > t_end:
-                print(f"[bench launcher] no result within GMR_BENCH_TIMEOUT={timeout:.0f} s: stopping all ranks", file=sys.stderr, flush=True)
-                rc = 124
-                break
-            time.sleep(0.05)
-    finally:
-        stop_all()
-    th.join(5.0)
-    if rc == 0 and not any(ln.lstrip().startswith("{") for ln in lines):
-        print("[bench launcher] every rank exited 0 but rank 0 printed no JSON line", file=sys.stderr, flush=True)
-        rc = 1
-    return rc
+    (the ONE JSON line) is relayed; the first non-zero exit of any rank ends the job with that code."""
+    from general_motion_retargeting_amd import launcher
+    return launcher.self_launch(n, [sys.executable, os.path.abspath(__file__)] + list(argv), "GMR_BENCH_TIMEOUT", 1500.0,
+                                require_stdout_prefix="{")
 
 
 def load_standin():

@@ -66,6 +66,9 @@ _SIGS = {
                                    C.c_void_p, C.c_void_p]),
     "gmr_fk_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_void_p]),
+    "gmr_fk_segment_min_z_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "gmr_fk_batch_segments": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     "gmr_smplx_create": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "gmr_smplx_destroy": (C.c_int, [C.c_void_p]),
     "gmr_smplx_rows": (C.c_int, [C.c_void_p]),
@@ -466,6 +469,22 @@ class FkHandle:
         mz = np.zeros(1, dtype=np.float32) if want_min_z else None
         check(lib().gmr_fk_batch(self.handle, B, _ptr(root_pos), _ptr(root_rot), _ptr(dof), _ptr(bp), _ptr(br), _ptr(mz)))
         return bp, br, (float(mz[0]) if want_min_z else None)
+
+    def fk_segments(self, root_pos, root_rot, dof, seg_start, want_pos=True):
+        """Many clips in one launch: rows [seg_start[g], seg_start[g + 1]) are clip g.  Returns (body_pos [B, nb, 3] or None,
+        seg_min_z [nseg]): the per-clip minimum of body_pos z (gmr_fk_batch_segments)."""
+        root_pos = np.ascontiguousarray(root_pos, dtype=np.float32)
+        root_rot = np.ascontiguousarray(root_rot, dtype=np.float32)
+        dof = np.ascontiguousarray(dof, dtype=np.float32)
+        seg_start = np.ascontiguousarray(seg_start, dtype=np.int32)
+        B, nseg = root_pos.shape[0], len(seg_start) - 1
+        if root_pos.shape != (B, 3) or root_rot.shape != (B, 4) or dof.shape != (B, self.ndof) or nseg < 0:
+            raise ValueError("shape mismatch in fk inputs")
+        bp = np.zeros((B, self.nbody, 3), dtype=np.float32) if want_pos else None
+        mz = np.zeros(max(nseg, 0), dtype=np.float32)
+        check(lib().gmr_fk_batch_segments(self.handle, B, _ptr(root_pos), _ptr(root_rot), _ptr(dof), nseg, _ptr(seg_start),
+                                          _ptr(bp), _ptr(mz)))
+        return bp, mz
 
     def fk_dev(self, B, d_root_pos, d_root_rot, d_dof, d_body_pos, d_body_rot=None, d_min_z=None, stream=None):
         check(lib().gmr_fk_batch_dev(self.handle, int(B), _d(d_root_pos), _d(d_root_rot), _d(d_dof), _d(d_body_pos),

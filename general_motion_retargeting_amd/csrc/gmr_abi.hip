@@ -43,6 +43,7 @@ extern "C" hipError_t gmr_ik_wide_attributes(int* num_regs, int* lds_bytes, int*
 extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree*, const gmr::FkTree*, int, const float*, const float*, const float*,
                                           float*, float*, float*, float*, hipStream_t);
 extern "C" int gmr_fk_blocks(int B);
+extern "C" hipError_t gmr_launch_fk_segment_min(const float*, int, const int32_t*, int, float*, hipStream_t);
 
 // up to this many streams a launch uses the 4-wave (main + 3 helpers) shape; measured crossover on MI355X
 // (tools/shape_sweep.py, G1): S=256 1.04M vs 0.93M frames/s, S=384 1.24M vs 1.40M (NW=4 vs NW=1): the switch
@@ -750,6 +751,55 @@ int gmr_fk_batch(gmr_fk_t* k, int B, const float* root_pos, const float* root_ro
         (e = hipMemcpy(body_pos, d + o_bp, b_bp, hipMemcpyDeviceToHost)) != hipSuccess ||
         (body_rot && (e = hipMemcpy(body_rot, d + o_br, b_br, hipMemcpyDeviceToHost)) != hipSuccess) ||
         (min_z && (e = hipMemcpy(min_z, d + o_mz, 4, hipMemcpyDeviceToHost)) != hipSuccess))
+      rc = fail(GMR_ERR_HIP, "kernel / D2H copy: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(d);
+  return rc;
+}
+
+int gmr_fk_segment_min_z_dev(gmr_fk_t* k, const float* d_body_pos, const int32_t* d_seg_start, int nseg, float* d_seg_min,
+                             void* stream) {
+  if (!k) return fail(GMR_ERR_ARG, "null fk handle");
+  if (nseg < 0) return fail(GMR_ERR_ARG, "negative nseg");
+  if (nseg == 0) return GMR_OK;
+  if (!d_body_pos || !d_seg_start || !d_seg_min) return fail(GMR_ERR_ARG, "null device buffer");
+  HIP_TRY(gmr_launch_fk_segment_min(d_body_pos, k->tree.nbody, d_seg_start, nseg, d_seg_min, (hipStream_t)stream));
+  return GMR_OK;
+}
+
+// Many clips in one launch: frames of clip g are rows [seg_start[g], seg_start[g + 1]) of the inputs.
+int gmr_fk_batch_segments(gmr_fk_t* k, int B, const float* root_pos, const float* root_rot, const float* dof, int nseg,
+                          const int32_t* seg_start, float* body_pos, float* seg_min_z) {
+  if (!k) return fail(GMR_ERR_ARG, "null fk handle");
+  if (B < 0 || nseg < 0) return fail(GMR_ERR_ARG, "negative B / nseg");
+  if (B == 0) { for (int g = 0; g < nseg && seg_min_z; g++) seg_min_z[g] = INFINITY; return GMR_OK; }
+  if (!root_pos || !root_rot || (k->tree.ndof > 0 && !dof)) return fail(GMR_ERR_ARG, "null host buffer");
+  if (nseg > 0 && (!seg_start || !seg_min_z)) return fail(GMR_ERR_ARG, "null segment buffers");
+  for (int g = 0; g < nseg; g++)
+    if (seg_start[g] < 0 || seg_start[g] > seg_start[g + 1] || seg_start[g + 1] > B) return fail(GMR_ERR_ARG, "seg_start must ascend within [0, B]");
+  const size_t nb = k->tree.nbody, nd = k->tree.ndof;
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  const size_t b_rp = (size_t)B * 12, b_rr = (size_t)B * 16, b_d = (size_t)B * nd * 4, b_bp = (size_t)B * nb * 12,
+               b_ss = (size_t)(nseg + 1) * 4, b_sm = (size_t)nseg * 4;
+  const size_t o_rp = 0, o_rr = o_rp + up(b_rp), o_d = o_rr + up(b_rr), o_bp = o_d + up(b_d), o_ss = o_bp + up(b_bp),
+               o_sm = o_ss + up(b_ss), total = o_sm + up(b_sm) + 256;
+  char* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, total));
+  int rc = GMR_OK;
+  hipError_t e;
+  if ((e = hipMemcpy(d + o_rp, root_pos, b_rp, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(d + o_rr, root_rot, b_rr, hipMemcpyHostToDevice)) != hipSuccess ||
+      (nd && (e = hipMemcpy(d + o_d, dof, b_d, hipMemcpyHostToDevice)) != hipSuccess) ||
+      (nseg && (e = hipMemcpy(d + o_ss, seg_start, b_ss, hipMemcpyHostToDevice)) != hipSuccess))
+    rc = fail(GMR_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
+  if (rc == GMR_OK)
+    rc = gmr_fk_batch_dev(k, B, (float*)(d + o_rp), (float*)(d + o_rr), (float*)(d + o_d), (float*)(d + o_bp), nullptr, nullptr, nullptr);
+  if (rc == GMR_OK && nseg)
+    rc = gmr_fk_segment_min_z_dev(k, (float*)(d + o_bp), (int32_t*)(d + o_ss), nseg, (float*)(d + o_sm), nullptr);
+  if (rc == GMR_OK) {
+    if ((e = hipDeviceSynchronize()) != hipSuccess ||
+        (body_pos && (e = hipMemcpy(body_pos, d + o_bp, b_bp, hipMemcpyDeviceToHost)) != hipSuccess) ||
+        (nseg && (e = hipMemcpy(seg_min_z, d + o_sm, b_sm, hipMemcpyDeviceToHost)) != hipSuccess))
       rc = fail(GMR_ERR_HIP, "kernel / D2H copy: %s", hipGetErrorString(e));
   }
   (void)hipFree(d);

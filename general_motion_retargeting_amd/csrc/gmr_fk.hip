@@ -410,7 +410,29 @@ __global__ __launch_bounds__(256) void min_reduce_kernel(const float* __restrict
   if (threadIdx.x == 0) out[0] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
 }
 
+// min over the frames [seg_start[g], seg_start[g + 1]) and all bodies of body_pos z: one block per segment (clip).
+// The dataset scripts' height adjustment is per clip (smplx_to_robot_dataset.py:118-126); with many clips
+// concatenated into one FK launch this is their reduction.  An empty segment yields +inf.
+__global__ __launch_bounds__(256) void fk_segment_min_kernel(const float* __restrict__ body_pos, int nbody,
+                                                              const int32_t* __restrict__ seg_start, float* __restrict__ seg_min) {
+  __shared__ float red[4];
+  const long long i0 = (long long)seg_start[blockIdx.x] * nbody, i1 = (long long)seg_start[blockIdx.x + 1] * nbody;
+  float z = INFINITY;
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) z = fminf(z, body_pos[3 * i + 2]);
+  for (int off = 32; off > 0; off >>= 1) z = fminf(z, __shfl_xor(z, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = z;
+  __syncthreads();
+  if (threadIdx.x == 0) seg_min[blockIdx.x] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+}
+
 }  // namespace gmr
+
+extern "C" hipError_t gmr_launch_fk_segment_min(const float* d_body_pos, int nbody, const int32_t* d_seg_start, int nseg,
+                                                float* d_seg_min, hipStream_t stream) {
+  if (nseg <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gmr::fk_segment_min_kernel, dim3(nseg), dim3(256), 0, stream, d_body_pos, nbody, d_seg_start, d_seg_min);
+  return hipGetLastError();
+}
 
 // blocks of a launch over B frames: one wave per 64 frames; also the size of the min-z partials
 extern "C" int gmr_fk_blocks(int B) { return (B + gmr::FK_BLOCK - 1) / gmr::FK_BLOCK; }

@@ -72,50 +72,66 @@ def read_bvh(filename) -> Bvh:
     nframes = None
     rows: List[np.ndarray] = []
     with open(filename, "r") as f:
-        for line in f:
-            if "HIERARCHY" in line or "MOTION" in line or "{" in line:
-                continue
-            m = re.match(r"\s*(ROOT|JOINT)\s+(\w+)", line)
-            if m:
-                names.append(m.group(2))
-                offsets.append([0.0, 0.0, 0.0])
-                parents.append(active)
-                active = len(parents) - 1
-                continue
-            if "}" in line:
-                if end_site:
-                    end_site = False
-                else:
-                    active = parents[active]
-                continue
-            m = re.match(r"\s*OFFSET\s+([\-\d\.e]+)\s+([\-\d\.e]+)\s+([\-\d\.e]+)", line)
-            if m:
-                if not end_site:
-                    offsets[active] = [float(v) for v in m.groups()]
-                continue
-            m = re.match(r"\s*CHANNELS\s+(\d+)", line)
-            if m:
-                channels = int(m.group(1))
-                if order is None:
-                    lo, hi = (0, 3) if channels == 3 else (3, 6)
-                    parts = line.split()[2 + lo: 2 + hi]
-                    if all(p in _CHANNEL_AXIS for p in parts):
-                        order = "".join(_CHANNEL_AXIS[p] for p in parts)
-                continue
-            if "End Site" in line:
-                end_site = True
-                continue
-            m = re.match(r"\s*Frames:\s+(\d+)", line)
-            if m:
-                nframes = int(m.group(1))
-                continue
-            m = re.match(r"\s*Frame Time:\s+([\d\.]+)", line)
-            if m:
-                frametime = float(m.group(1))
-                continue
-            vals = line.strip().split(" ")
-            if vals and vals != [""]:
-                rows.append(np.array([float(v) for v in vals]))
+        lines = f.readlines()
+    motion_at = None
+    for li, line in enumerate(lines):
+        if "HIERARCHY" in line or "MOTION" in line or "{" in line:
+            continue
+        m = re.match(r"\s*(ROOT|JOINT)\s+(\w+)", line)
+        if m:
+            names.append(m.group(2))
+            offsets.append([0.0, 0.0, 0.0])
+            parents.append(active)
+            active = len(parents) - 1
+            continue
+        if "}" in line:
+            if end_site:
+                end_site = False
+            else:
+                active = parents[active]
+            continue
+        m = re.match(r"\s*OFFSET\s+([\-\d\.e]+)\s+([\-\d\.e]+)\s+([\-\d\.e]+)", line)
+        if m:
+            if not end_site:
+                offsets[active] = [float(v) for v in m.groups()]
+            continue
+        m = re.match(r"\s*CHANNELS\s+(\d+)", line)
+        if m:
+            channels = int(m.group(1))
+            if order is None:
+                lo, hi = (0, 3) if channels == 3 else (3, 6)
+                parts = line.split()[2 + lo: 2 + hi]
+                if all(p in _CHANNEL_AXIS for p in parts):
+                    order = "".join(_CHANNEL_AXIS[p] for p in parts)
+            continue
+        if "End Site" in line:
+            end_site = True
+            continue
+        m = re.match(r"\s*Frames:\s+(\d+)", line)
+        if m:
+            nframes = int(m.group(1))
+            continue
+        m = re.match(r"\s*Frame Time:\s+([\d\.]+)", line)
+        if m:
+            frametime = float(m.group(1))
+            if nframes is not None and frametime is not None:
+                motion_at = li + 1      # everything below is the motion block: parsed in one go, not line by line
+                break
+            continue
+        vals = line.strip().split(" ")
+        if vals and vals != [""]:
+            rows.append(np.array([float(v) for v in vals]))
+    if motion_at is not None:
+        # The motion block: one row of numbers per frame.  Parsed with one C call instead of a Python loop with five
+        # regular-expression attempts per line (the loader's cost is what bounds the dataset driver: tools/dataset_probe.py);
+        # the same correctly-rounded doubles as float().
+        body = [ln for ln in lines[motion_at:] if ln.strip()]
+        if body:
+            ncol = len(body[0].split())
+            flat = np.fromstring("".join(body), dtype=np.float64, sep=" ")
+            if ncol == 0 or flat.size % ncol != 0:
+                raise ValueError(f"{filename}: ragged motion block")
+            rows = list(flat.reshape(-1, ncol))
     n = len(parents)
     off = np.array(offsets, dtype=np.float64).reshape(n, 3)
     data = np.stack(rows[:nframes]) if rows else np.zeros((0, 3 + 3 * n))
@@ -160,16 +176,21 @@ def remove_quat_discontinuities(rotations):
 
 
 def quat_fk(lrot, lpos, parents):
-    """Global (rot, pos) from local ones, parents before children (utils.py:88-103)."""
+    """Global (rot, pos) from local ones, parents before children (utils.py:88-103).  The joints of one tree depth are
+    composed in one vectorised step (the same operations per joint as the reference's joint-by-joint loop: same bits)."""
     J = len(parents)
     gr = np.empty_like(lrot)
     gp = np.empty_like(lpos)
     gr[..., 0, :] = lrot[..., 0, :]
     gp[..., 0, :] = lpos[..., 0, :]
+    depth = np.zeros(J, dtype=int)
     for i in range(1, J):
-        p = int(parents[i])
-        gp[..., i, :] = _quat_mul_vec(gr[..., p, :], lpos[..., i, :]) + gp[..., p, :]
-        gr[..., i, :] = _quat_mul(gr[..., p, :], lrot[..., i, :])
+        depth[i] = depth[int(parents[i])] + 1
+    for d in range(1, int(depth.max()) + 1 if J > 1 else 1):
+        idx = np.nonzero(depth == d)[0]
+        par = np.asarray(parents)[idx].astype(int)
+        gp[..., idx, :] = _quat_mul_vec(gr[..., par, :], lpos[..., idx, :]) + gp[..., par, :]
+        gr[..., idx, :] = _quat_mul(gr[..., par, :], lrot[..., idx, :])
     return gr, gp
 
 

@@ -130,6 +130,19 @@ class SmplxBodyModel:
         return SmplxOutput(global_orient=full[:, 0].copy(), full_pose=full.reshape(N, 3 * J), joints=joints)
 
 
+_BODY_MODELS: Dict[tuple, "SmplxBodyModel"] = {}
+
+
+def body_model_for(smplx_body_model_path, gender) -> "SmplxBodyModel":
+    """The body model of (path, gender), read once per process (the reference calls ``smplx.create`` per file, :14-22;
+    a dataset run opens thousands of files)."""
+    key = (os.path.abspath(str(smplx_body_model_path)), str(gender))
+    bm = _BODY_MODELS.get(key)
+    if bm is None:
+        bm = _BODY_MODELS[key] = SmplxBodyModel.from_model_path(smplx_body_model_path, gender=str(gender))
+    return bm
+
+
 def load_smpl_file(smpl_file):
     return np.load(smpl_file, allow_pickle=False)
 
@@ -137,7 +150,7 @@ def load_smpl_file(smpl_file):
 def load_smplx_file(smplx_file, smplx_body_model_path):
     """Reference :12-41: returns ``(smplx_data, body_model, smplx_output, human_height)``."""
     smplx_data = np.load(smplx_file, allow_pickle=False)
-    body_model = SmplxBodyModel.from_model_path(smplx_body_model_path, gender=str(smplx_data["gender"]))
+    body_model = body_model_for(smplx_body_model_path, str(smplx_data["gender"]))
     smplx_output = body_model(betas=smplx_data["betas"], global_orient=smplx_data["root_orient"],
                               body_pose=smplx_data["pose_body"], transl=smplx_data["trans"])
     betas = np.asarray(smplx_data["betas"])

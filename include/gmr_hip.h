@@ -170,6 +170,14 @@ int gmr_fk_batch_dev(gmr_fk_t* fk, int B, const float* d_root_pos, const float* 
 int gmr_fk_batch(gmr_fk_t* fk, int B, const float* root_pos, const float* root_rot, const float* dof,
                  float* body_pos, float* body_rot, float* min_z);
 
+/* Many clips in ONE launch (the dataset drivers): the frames of clip g are rows [seg_start[g], seg_start[g + 1]) of the
+ * inputs; seg_min_z[g] = min over the clip's frames and bodies of body_pos z -- the per-clip reduction of the height
+ * adjustment (smplx_to_robot_dataset.py:118-126), +inf for an empty clip.  body_pos may be NULL (only the minima wanted). */
+int gmr_fk_segment_min_z_dev(gmr_fk_t* fk, const float* d_body_pos, const int32_t* d_seg_start, int nseg, float* d_seg_min,
+                             void* stream);
+int gmr_fk_batch_segments(gmr_fk_t* fk, int B, const float* root_pos, const float* root_rot, const float* dof, int nseg,
+                          const int32_t* seg_start /* [nseg + 1] */, float* body_pos, float* seg_min_z /* [nseg] */);
+
 /* ---- N1: SMPL-X frame extraction (the step in front of the loop) ---------- */
 /* A kinematic tree of J <= 64 joints (parents[j] < j, joint 0 the root) and the joints whose poses are
  * wanted: sel[nsel] (one output row each, in this order; nsel = 0 -> all J joints, row = joint).  For the

@@ -52,7 +52,7 @@ def test_self_launch_fails_fast_when_a_rank_dies():
     t0 = time.time()
     r = _run(["--gpus", "2"] + SMALL, "tcp", {"GMR_STANDIN_FAIL_RANK": "1"})
     assert r.returncode == 7, (r.returncode, r.stderr[-2000:])
-    assert "rank 1 exited with code 7" in r.stderr
+    assert "rank 1 exited with code 7" in r.stderr and "[launcher]" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert time.time() - t0 < 120                                    # the surviving rank was stopped, not waited for
 

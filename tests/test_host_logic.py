@@ -208,38 +208,40 @@ def test_dataset_drivers_follow_the_reference_file_semantics(tmp_path, capsys):
     assert dataset.load_hard_motions([str(hard), str(tmp_path / "missing.txt")]) == ["hard_one_stageii"]
     calls = []
 
-    def fake_retarget(paths, smplx_folder, robot):
+    def fake_load(path):
+        if "broken" in path:
+            raise ValueError("bad zip file")                      # a file that fails to load: printed + skipped (:62-76)
+        return {"trans": np.zeros((2, 3)), "path": path}
+
+    def fake_retarget(clips, paths):
         calls.append(list(paths))
-        out = []
-        for p in paths:
-            if "broken" in p:
-                out.append(None)                                  # a file that failed to load: printed + skipped
-                continue
-            out.append({"fps": 30.0, "root_pos": np.zeros((2, 3)), "root_rot": np.zeros((2, 4)), "dof_pos": np.zeros((2, 29)),
-                        "local_body_pos": np.zeros((2, 38, 3), np.float32), "link_body_list": ["pelvis"], "extra": 1})
-        return out
+        assert [c["path"] for c in clips] == list(paths)
+        return [{"fps": 30.0, "root_pos": np.zeros((2, 3)), "root_rot": np.zeros((2, 4)), "dof_pos": np.zeros((2, 29)),
+                 "local_body_pos": np.zeros((2, 38, 3), np.float32), "link_body_list": ["pelvis"], "extra": 1} for _ in paths]
 
     n = dataset.run_smplx_dataset(str(src), str(tgt), "unitree_g1", "models", False, [str(hard)], batch_files=2,
-                                  retarget=fake_retarget)
+                                  retarget=fake_retarget, load=fake_load, loader_workers=2)
     got = sorted(str(p.relative_to(tgt)) for p in tgt.rglob("*.pkl"))
     assert got == ["A/walk_10_stageii.pkl", "A/walk_2_stageii.pkl", "B/run_1.pkl"] and n == 3
     flat = [os.path.relpath(p, src) for c in calls for p in c]
-    assert all(len(c) <= 2 for c in calls)                        # files grouped into launches of <= batch_files
-    a_files = [f for f in flat if f.startswith("A/")]
+    assert all(len(c) <= 2 for c in calls)                        # clips grouped into launches of <= batch_files
+    all_jobs, kept = dataset.list_smplx_jobs(str(src), str(tgt / "nothing_here"), False, ["hard_one_stageii"])
+    a_files = [os.path.relpath(s_, src) for s_, _ in kept if "/A/" in s_]
     assert a_files == ["A/walk_2_stageii.npz", "A/walk_10_stageii.npz"]   # natsorted, *_stagei.npz and non-motion files skipped
+    assert sorted(flat) == ["A/walk_10_stageii.npz", "A/walk_2_stageii.npz", "B/run_1.pkl"]
     assert not any(x in f for f in flat for x in ("BMLrub", "crawl", "upstairs", "hard_one", "stagei.npz"))
     with open(tgt / "B" / "run_1.pkl", "rb") as f:
         md = pickle.load(f)
     assert list(md) == ["fps", "root_pos", "root_rot", "dof_pos", "local_body_pos", "link_body_list"]
     out = capsys.readouterr().out
-    assert "full args_list: 8" in out and "new args_list: 4" in out and "Processed 3/4" in out
+    assert "full args_list: 8" in out and "new args_list: 4" in out and "Processed 3/4" in out and "Error loading" in out
     # second run: everything that exists is skipped; --override redoes it
     calls.clear()
-    dataset.run_smplx_dataset(str(src), str(tgt), "unitree_g1", "models", False, [str(hard)], retarget=fake_retarget)
-    assert [os.path.relpath(p, src) for c in calls for p in c] == ["B/broken.npz"]
-    calls.clear()
-    dataset.run_smplx_dataset(str(src), str(tgt), "unitree_g1", "models", True, [str(hard)], retarget=fake_retarget)
-    assert len([p for c in calls for p in c]) == 4
+    assert dataset.run_smplx_dataset(str(src), str(tgt), "unitree_g1", "models", False, [str(hard)], retarget=fake_retarget,
+                                     load=fake_load, loader_workers=0) == 0
+    assert calls == []                                            # only the broken file was left, and it does not load
+    dataset.run_smplx_dataset(str(src), str(tgt), "unitree_g1", "models", True, [str(hard)], retarget=fake_retarget, load=fake_load)
+    assert len([p for c in calls for p in c]) == 3
     # BVH driver: sorted walk, .bvh only, skip message, the BVH script's key order
     bsrc, btgt = tmp_path / "lafan", tmp_path / "lafan_out"
     for f in ["walk1_subject1.bvh", "aiming1_subject1.bvh", "readme.md", "sub/run2_subject4.bvh"]:
@@ -249,13 +251,13 @@ def test_dataset_drivers_follow_the_reference_file_semantics(tmp_path, capsys):
     (btgt / "walk1_subject1.pkl").write_bytes(b"old")
     seen = []
 
-    def fake_bvh(paths, robot):
+    def fake_bvh(clips, paths):
         seen.extend(paths)
         return [{"fps": 30, "root_pos": np.zeros((1, 3)), "root_rot": np.zeros((1, 4)), "dof_pos": np.zeros((1, 29)),
                  "local_body_pos": np.zeros((1, 38, 3), np.float32), "link_body_list": ["pelvis"]} for _ in paths]
 
-    assert dataset.run_bvh_dataset(str(bsrc), str(btgt), "unitree_g1", retarget=fake_bvh) == 2
-    assert [os.path.relpath(p, bsrc) for p in seen] == ["aiming1_subject1.bvh", "sub/run2_subject4.bvh"]
+    assert dataset.run_bvh_dataset(str(bsrc), str(btgt), "unitree_g1", retarget=fake_bvh, load=lambda f: np.zeros((1, 15, 7))) == 2
+    assert sorted(os.path.relpath(p, bsrc) for p in seen) == ["aiming1_subject1.bvh", "sub/run2_subject4.bvh"]
     assert "Skipping" in capsys.readouterr().out and (btgt / "walk1_subject1.pkl").read_bytes() == b"old"
     with open(btgt / "sub" / "run2_subject4.pkl", "rb") as f:
         assert list(pickle.load(f)) == ["root_pos", "root_rot", "dof_pos", "local_body_pos", "fps", "link_body_list"]
