@@ -640,49 +640,15 @@ int gmr_fk_create(int nbody, const int32_t* parent, const float* local_t, const 
     for (int a = 0; a < 3; a++) { r.t[a] = t.local_t[3 * b + a]; r.axis[a] = t.axis[3 * b + a]; }
     for (int a = 0; a < 4; a++) r.r[a] = t.local_r[4 * b + a];
     r.dof_idx = t.dof_idx[b];
-    r.pad = 0;
+    r.next_park = 0;
     r.meta = (t.dof_idx[b] >= 0 ? 1u : 0u) | ((uint32_t)(t.load_slot[b] + 1) << 8) | ((uint32_t)(t.save_slot[b] + 1) << 16) |
              ((uint32_t)t.parent[b] << 24);
   }
-  // the split walk: per-wavefront body lists with their own records (slots numbered block-wide)
+  // the split walk: per-wavefront body lists with their own records (gmr_fk_tree.h)
   {
-    int lists[gmr::FK_MAX_WAVES][gmr::FK_MAX_BODIES], nlist[gmr::FK_MAX_WAVES] = {0};
-    int par[gmr::FK_MAX_BODIES];
-    for (int b = 0; b < nbody; b++) par[b] = b == 0 ? -1 : parent[b];
     const int maxw = getenv("GMR_FK_WAVES") ? std::max(1, std::min(gmr::FK_MAX_WAVES, atoi(getenv("GMR_FK_WAVES")))) : gmr::FK_MAX_WAVES;
-    t.nwave = nbody >= 8 ? gmr::fk_split_tree(nbody, par, maxw, lists, nlist) : 1;
-    if (t.nwave == 1) { nlist[0] = nbody; for (int b = 0; b < nbody; b++) lists[0][b] = b; }
-    bool owned[gmr::FK_MAX_BODIES] = {false};
-    int nrec = 0, nslot = 0;
-    for (int w = 0; w < t.nwave; w++) {
-      t.wave_start[w] = nrec;
-      const int n = nlist[w];
-      int slot_of[gmr::FK_MAX_BODIES];
-      for (int b = 0; b < nbody; b++) slot_of[b] = -1;
-      bool spare_used = false;                    // a wavefront's first parked parent lives in registers (slot code 254)
-      for (int i = 1; i < n; i++) {               // a parent that is not the body walked just before is reloaded from a slot
-        const int p = par[lists[w][i]];
-        if (lists[w][i - 1] != p && slot_of[p] < 0) {
-          if (!spare_used) { slot_of[p] = 254; spare_used = true; }
-          else slot_of[p] = nslot++;
-        }
-      }
-      for (int i = 0; i < n; i++) {
-        const int b = lists[w][i];
-        gmr::FkBodyRec r = t.rec[b];
-        const int p = b == 0 ? 0 : par[b];
-        const int src = (i == 0 || lists[w][i - 1] == p) ? -1 : slot_of[p];
-        const bool own = !owned[b];
-        owned[b] = true;
-        r.meta = (r.meta & 0xFu) | (own ? 16u : 0u) | ((uint32_t)(src + 1) << 8) | ((uint32_t)(slot_of[b] + 1) << 16) | ((uint32_t)b << 24);
-        if (nrec >= 2 * gmr::FK_MAX_BODIES) { delete k; return fail(GMR_ERR_ARG, "split walk: too many records"); }
-        t.wrec[nrec++] = r;
-      }
-    }
-    t.wave_start[t.nwave] = nrec;
-    for (int w = t.nwave + 1; w <= gmr::FK_MAX_WAVES; w++) t.wave_start[w] = nrec;
-    t.nslot_split = nslot;
-    for (int b = 0; b < nbody; b++) if (!owned[b]) { delete k; return fail(GMR_ERR_ARG, "split walk: body %d not covered", b); }
+    const char* why = gmr::fk_build_split(t, parent, maxw);
+    if (why) { delete k; return fail(GMR_ERR_ARG, "split walk: %s", why); }
   }
   hipError_t e;
   if ((e = hipMalloc((void**)&k->d_tree, sizeof(gmr::FkTree))) != hipSuccess ||

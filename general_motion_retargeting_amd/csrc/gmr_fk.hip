@@ -291,27 +291,44 @@ __global__ __launch_bounds__(64 * FK_MAX_WAVES) void fk_split_kernel(const FkTre
   const int row = nb * 3, rrow = nb * 4;
   float* outb = fsm + tree->nslot_split * 7 * 64;
   float* outr = outb + 64 * row;
+  float* xtra = outr + (body_rot ? 64 * rrow : 0) + tid;      // extra angle columns [k][lane] (FkTree::nextra)
   float* orow = outb + tid * row;
   float* rrow_p = outr + tid * rrow;
   const float* drow = dof + fc * ndof;
   const int i0 = tree->wave_start[wave], i1 = tree->wave_start[wave + 1];
   float zmin = INFINITY;
-  // park the joint angles of the bodies this wavefront stores, each in the staging slot its position will overwrite:
-  // the loads of a lane's own dof row, all issued back to back (see fk_batch_kernel)
-#pragma unroll 8
-  for (int i = i0; i < i1; i++) {
-    const uint32_t m = tree->wrec[i].meta;
-    const int d = tree->wrec[i].dof_idx;
-    if ((m & 17u) == 17u) orow[3 * (m >> 24)] = drow[d];
+  // Every joint angle this wavefront needs, read from the lane's dof row in ONE batch -- all loads issued back to back,
+  // one wait -- and parked in LDS (FkTree::wave_park): the x slot of the body's own position in the lane's staging row, a
+  // free y / z slot for an ancestor another wavefront stores, or an extra column.  The frame's root pose travels with the
+  // same batch.  (The loop this replaces loaded, waited and stored angle by angle behind two dependent scalar loads
+  // each -- the compiler could not batch them -- : a quarter of a block's lifetime was that serial chain.)
+  const float rpx = root_pos[fc * 3], rpy = root_pos[fc * 3 + 1], rpz = root_pos[fc * 3 + 2];
+  const f4 rrot = {root_rot[fc * 4], root_rot[fc * 4 + 1], root_rot[fc * 4 + 2], root_rot[fc * 4 + 3]};
+  {
+    const uint32_t* pk = tree->wave_park[wave];
+    for (int c = 0; c < 32; c += 16) {
+      uint32_t w[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) w[k] = pk[c + k];
+      if (w[0] == 0xffffffffu) break;
+      float a[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) a[k] = w[k] != 0xffffffffu ? drow[w[k] & 0xffffu] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        if (w[k] != 0xffffffffu) *((w[k] >> 31) ? xtra + 64 * ((w[k] >> 16) & 0x7fffu) : orow + (w[k] >> 16)) = a[k];
+    }
   }
   float cpx, cpy, cpz;
   f4 crot;
   float spx = 0.0f, spy = 0.0f, spz = 0.0f;        // the wavefront's first parked parent stays in registers (slot code 254):
   f4 srot = {0.0f, 0.0f, 0.0f, 1.0f};              // for the shipped trees no LDS slot is left, one more block fits a CU
+  float ang_nxt = 0.0f;
   {
     const FkBodyRec r0 = tree->wrec[i0];           // body 0 opens every list
-    const float px = root_pos[fc * 3], py = root_pos[fc * 3 + 1], pz = root_pos[fc * 3 + 2];
-    const f4 rot = {root_rot[fc * 4], root_rot[fc * 4 + 1], root_rot[fc * 4 + 2], root_rot[fc * 4 + 3]};
+    if (r0.next_park >> 31) ang_nxt = *((r0.next_park & 0x40000000u) ? xtra + 64 * (r0.next_park & 0xffffu) : orow + (r0.next_park & 0x3fffffffu));
+    const float px = rpx, py = rpy, pz = rpz;
+    const f4 rot = rrot;
     cpx = px; cpy = py; cpz = pz; crot = rot;
     const int dst = (int)((r0.meta >> 16) & 255u) - 1;
     if (dst == 254) { spx = px; spy = py; spz = pz; srot = rot; }
@@ -326,14 +343,20 @@ __global__ __launch_bounds__(64 * FK_MAX_WAVES) void fk_split_kernel(const FkTre
     }
   }
   FkBodyRec nxt = tree->wrec[i0 + 1 < i1 ? i0 + 1 : i0];
+#ifdef GMR_FK_EXP_NOWALK
+  for (int i = i1; i < i1; i++) {
+#else
   for (int i = i0 + 1; i < i1; i++) {
+#endif
     const FkBodyRec cur = nxt;                     // one 64-byte scalar load per body, issued one body ahead
+    // (the same record through the vector memory path -- a broadcast read straight into vector registers, which is
+    //  where the packed FP32 instructions need it -- measured slower: 0.294 vs 0.241 ms)
     nxt = tree->wrec[i + 1 < i1 ? i + 1 : i];
     const int j = (int)(cur.meta >> 24);
     const int src = (int)((cur.meta >> 8) & 255u) - 1, dst = (int)((cur.meta >> 16) & 255u) - 1;
     const bool own = cur.meta & 16u;
-    float ang = 0.0f;
-    if (cur.meta & 1u) ang = own ? orow[3 * j] : drow[cur.dof_idx];    // (an ancestor another wavefront stores: read directly)
+    const float ang = ang_nxt;                     // parked angle of this body, read while the previous body was walked
+    if (cur.next_park >> 31) ang_nxt = *((cur.next_park & 0x40000000u) ? xtra + 64 * (cur.next_park & 0xffffu) : orow + (cur.next_park & 0x3fffffffu));
     float ppx = cpx, ppy = cpy, ppz = cpz;
     f4 prot = crot;
     if (src == 254) { ppx = spx; ppy = spy; ppz = spz; prot = srot; }
@@ -360,6 +383,9 @@ __global__ __launch_bounds__(64 * FK_MAX_WAVES) void fk_split_kernel(const FkTre
     }
   }
   __syncthreads();
+#ifdef GMR_FK_EXP_NOFLUSH
+  if (B > 0) { if (zmin == 12345.f) body_pos[0] = outb[threadIdx.x]; return; }
+#endif
   // the block's output is one contiguous range of body_pos (and body_rot): all wavefronts stream it out, 16 B per lane
   const int nthr = 64 * nwave, t = threadIdx.x;
   const long long f0 = (long long)blockIdx.x * 64;
@@ -476,7 +502,7 @@ extern "C" hipError_t gmr_launch_fk_batch(const gmr::FkTree* d_tree, const gmr::
     }
   }
   // several wavefronts per block when the tree splits (gmr_fk_create) and the slots of the split walk fit beside the staging area
-  const size_t smem_split = (size_t)h_tree->nslot_split * 7 * 64 * sizeof(float) + stage_bytes;
+  const size_t smem_split = (size_t)h_tree->nslot_split * 7 * 64 * sizeof(float) + stage_bytes + (size_t)h_tree->nextra * 64 * sizeof(float);
   if (staged && h_tree->nwave > 1 && smem_split <= 160 * 1024 - 8192 && (smem_split <= 64 * 1024 || fk_opt_in_large_lds() == hipSuccess))
     hipLaunchKernelGGL(gmr::fk_split_kernel, dim3(blocks), dim3(64 * h_tree->nwave), smem_split, stream, d_tree, B,
                        d_root_pos, d_root_rot, d_dof, d_body_pos, d_body_rot, d_min_z ? d_min_part : nullptr);

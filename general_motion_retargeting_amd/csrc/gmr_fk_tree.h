@@ -1,6 +1,9 @@
 // gmr_fk_tree.h -- device-side tree of the float32 post-hoc FK (reference KinematicsModel arrays).
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 namespace gmr {
 
@@ -16,7 +19,9 @@ struct FkBodyRec {
   float r[4];                 // local rotation xyzw, un-normalised
   double axis[3];             // normalised hinge axis (float64)
   int32_t dof_idx;            // first dof of the joint or -1
-  uint32_t pad;
+  uint32_t next_park;         // split walk: where the NEXT body of the wavefront's list finds its joint angle (read one body
+                              // ahead) -- [31] that body has a joint, [30] extra column (index in [29:0]) instead of a float
+                              // offset in the lane's staging row
 };
 static_assert(sizeof(FkBodyRec) == 64, "one record = one s_load_dwordx16");
 
@@ -41,6 +46,11 @@ struct FkTree {
   int nwave, nslot_split;
   int wave_start[5];
   FkBodyRec wrec[2 * FK_MAX_BODIES];
+  // the joint angles a wavefront needs, read from the frame's dof row in ONE batch before the walk and parked in LDS:
+  // [15:0] dof, [30:16] float offset of the parking slot in the lane's staging row, or -- [31] set -- the index of an
+  // extra column [index][lane] behind the staging area (nextra columns per block); 0xffffffff ends the list
+  uint32_t wave_park[FK_MAX_WAVES][32];
+  int nextra;
 };
 
 // Partition of the tree for the split walk (host side, gmr_fk_create).  `parent[b] < b`.  Returns the number of
@@ -115,6 +125,90 @@ inline int fk_split_tree(int nbody, const int* parent, int maxw, int lists[][FK_
   }
   if (nw == 0) { nlist[0] = 0; for (int b = 0; b < nbody; b++) lists[0][nlist[0]++] = b; nw = 1; }
   return nw;
+}
+
+
+// Records of the split walk (host side, gmr_fk_create): per-wavefront body lists with their own records, slots numbered
+// block-wide, and the parking slots of the joint angles.  `t.rec`, `t.nbody` must be filled.  Returns nullptr or why
+// the tree cannot be described (the caller fails); a tree that merely does not split gets nwave = 1.
+inline const char* fk_build_split(FkTree& t, const int32_t* parent, int maxw) {
+  const int nbody = t.nbody;
+  int lists[FK_MAX_WAVES][FK_MAX_BODIES], nlist[FK_MAX_WAVES] = {0};
+  int par[FK_MAX_BODIES];
+  for (int b = 0; b < nbody; b++) par[b] = b == 0 ? -1 : parent[b];
+  t.nwave = nbody >= 8 ? fk_split_tree(nbody, par, maxw, lists, nlist) : 1;
+  if (t.nwave == 1) { nlist[0] = nbody; for (int b = 0; b < nbody; b++) lists[0][b] = b; }
+  bool owned[FK_MAX_BODIES] = {false};
+  int nrec = 0, nslot = 0;
+  for (int w = 0; w < t.nwave; w++) {
+    t.wave_start[w] = nrec;
+    const int n = nlist[w];
+    int slot_of[FK_MAX_BODIES];
+    for (int b = 0; b < nbody; b++) slot_of[b] = -1;
+    bool spare_used = false;                    // a wavefront's first parked parent lives in registers (slot code 254)
+    for (int i = 1; i < n; i++) {               // a parent that is not the body walked just before is reloaded from a slot
+      const int p = par[lists[w][i]];
+      if (lists[w][i - 1] != p && slot_of[p] < 0) {
+        if (!spare_used) { slot_of[p] = 254; spare_used = true; }
+        else slot_of[p] = nslot++;
+      }
+    }
+    for (int i = 0; i < n; i++) {
+      const int b = lists[w][i];
+      FkBodyRec r = t.rec[b];
+      const int p = b == 0 ? 0 : par[b];
+      const int src = (i == 0 || lists[w][i - 1] == p) ? -1 : slot_of[p];
+      const bool own = !owned[b];
+      owned[b] = true;
+      r.meta = (r.meta & 0xFu) | (own ? 16u : 0u) | ((uint32_t)(src + 1) << 8) | ((uint32_t)(slot_of[b] + 1) << 16) | ((uint32_t)b << 24);
+      if (nrec >= 2 * FK_MAX_BODIES) return "too many records";
+      t.wrec[nrec++] = r;
+    }
+  }
+  t.wave_start[t.nwave] = nrec;
+  for (int w = t.nwave + 1; w <= FK_MAX_WAVES; w++) t.wave_start[w] = nrec;
+  t.nslot_split = nslot;
+  // Where every joint angle of a wavefront's list is parked in the lane's staging row (read in one batch before the
+  // walk): a body this wavefront stores -- the x slot of its own position (overwritten by that position right after
+  // the angle was consumed); an ancestor another wavefront stores -- a y / z slot of a body this wavefront stores
+  // LATER in its list (free until then), or, when those run out, an extra LDS column of the block.
+  bool park_ok = true;
+  memset(t.wave_park, 0xff, sizeof t.wave_park);
+  t.nextra = 0;
+  for (int w = 0; w < t.nwave && park_ok; w++) {
+    const int i0 = t.wave_start[w], i1 = t.wave_start[w + 1];
+    int park_of[2 * FK_MAX_BODIES];
+    int npark = 0, next_free = i0, sub = 1;     // candidate: slot `sub` (1 = y, 2 = z) of the owned record `next_free`
+    for (int i = i0; i < i1; i++) {
+      const FkBodyRec& r = t.wrec[i];
+      park_of[i - i0] = -1;
+      if (!(r.meta & 1u)) continue;
+      const int b = (int)(r.meta >> 24);
+      int off = -1;
+      if (r.meta & 16u) off = 3 * b;
+      else {
+        for (;;) {
+          if (next_free <= i) { next_free = i + 1; sub = 1; }
+          if (next_free >= i1) break;
+          if (!(t.wrec[next_free].meta & 16u)) { next_free++; sub = 1; continue; }
+          off = 3 * (int)(t.wrec[next_free].meta >> 24) + sub;
+          if (++sub > 2) { next_free++; sub = 1; }
+          break;
+        }
+      }
+      if (npark >= 32 || r.dof_idx < 0 || r.dof_idx > 0xffff || off >= 0x8000) { park_ok = false; break; }
+      const uint32_t code = off >= 0 ? (uint32_t)off : (0x8000u | (uint32_t)t.nextra++);      // (no free slot: an extra column)
+      park_of[i - i0] = (int)code;
+      t.wave_park[w][npark++] = (uint32_t)r.dof_idx | (code << 16);
+    }
+    for (int i = i0; i < i1 && park_ok; i++) {
+      const int c = i + 1 < i1 ? park_of[i + 1 - i0] : -1;
+      t.wrec[i].next_park = c < 0 ? 0u : (0x80000000u | ((c & 0x8000) ? (0x40000000u | (uint32_t)(c & 0x7fff)) : (uint32_t)c));
+    }
+  }
+  if (!park_ok) t.nwave = 1;
+  for (int b = 0; b < nbody; b++) if (!owned[b]) return "a body is not covered";
+  return nullptr;
 }
 
 }  // namespace gmr
