@@ -58,6 +58,7 @@ template <class DimsRef>
 __device__ __forceinline__ void fk_wide(DimsRef D, double* sm, const char* __restrict__ img, int lane, Prof& pr,
                                         bool root_is_unit = false) {
   PROF_BEGIN(pr);
+  lane = fresh_lane(lane);     // (lane predicates of this phase are computed here and die with it: gmr_device_math.h)
   const int nb = D.nb;
   double* q = sm + LD.q;
   d3 pos = {0, 0, 0}, ax = {0, 0, 0};
@@ -113,6 +114,7 @@ __device__ __forceinline__ void fk_wide(DimsRef D, double* sm, const char* __res
 // residuals of the stage's tasks and their unweighted norm (motion_retarget.py:188-200); lane = task
 __device__ __forceinline__ double errors_wide(double* sm, uint32_t taskw, int K, int lane, Prof& pr) {
   PROF_BEGIN(pr);
+  lane = fresh_lane(lane);     // (lane predicates of this phase are computed here and die with it: gmr_device_math.h)
   double ss = 0.0;
   if (lane < K) {
     const int b = taskw & 255u, h = taskw >> 8;
@@ -139,6 +141,7 @@ __device__ __forceinline__ double errors_wide(double* sm, uint32_t taskw, int K,
 __device__ __forceinline__ double jlog_wide(double* sm, const char* __restrict__ img, int stage, int K, double lm_damping,
                                             int lane, Prof& pr) {
   PROF_BEGIN(pr);
+  lane = fresh_lane(lane);     // (lane predicates of this phase are computed here and die with it: gmr_device_math.h)
   double mu = 0.0;
   if (lane < K) {
     const double* w = img_at<double>(img, IM.task[stage]) + 2 * lane;
@@ -170,6 +173,7 @@ __device__ __forceinline__ double jlog_wide(double* sm, const char* __restrict__
 
 // (b) virtual lane = (task, dof) pair: weighted task-Jacobian column W_k (-Jl^-1(e_k)) J_body[:, d]
 __device__ __forceinline__ void pairs_wide(double* sm, const char* __restrict__ img, int stage, int P, int lane) {
+  lane = fresh_lane(lane);     // (lane predicates of this phase are computed here and die with it: gmr_device_math.h)
   double* Jw = sm + LD.Jw;
   double* cpart = sm + LD.cpart;
   const double* X = sm + LD.xa;
@@ -219,6 +223,7 @@ __device__ __forceinline__ void pairs_wide(double* sm, const char* __restrict__ 
 template <class DimsRef>
 __device__ __forceinline__ void cvec_wide(DimsRef D, double* sm, const char* __restrict__ img, int stage,
                                           double limit_gain, int lane) {
+  lane = fresh_lane(lane);     // (lane predicates of this phase are computed here and die with it: gmr_device_math.h)
   const double* cpart = sm + LD.cpart;
   if (lane < D.nv) {
     const uint32_t* ci = img_at<uint32_t>(img, IM.cidx[stage]) + lane;
@@ -257,6 +262,7 @@ __device__ __forceinline__ double dot6v(const double* a, const double* b) {
 
 __device__ __forceinline__ void hacc_wide(double* sm, const char* __restrict__ img, int items_off, int ntrip, double diag,
                                           int lane) {
+  lane = fresh_lane(lane);     // (lane predicates of this phase are computed here and die with it: gmr_device_math.h)
   double* __restrict__ H = sm + LD.H;
   char* __restrict__ Hb = reinterpret_cast<char*>(H);
   const char* __restrict__ Jb = reinterpret_cast<const char*>(sm + LD.Jw);
@@ -313,11 +319,12 @@ __device__ __forceinline__ void hacc_wide(double* sm, const char* __restrict__ i
 struct RowState { unsigned long long lower, upper; };
 
 template <class DimsRef>
-__device__ __forceinline__ int solve_rows(DimsRef D, double* sm, const char* __restrict__ img, int lane_in,
+__device__ __forceinline__ int solve_rows(DimsRef D, double* sm, const char* __restrict__ img, const int lane_in0,
                                           RowState& bs, Prof& pr) {
   constexpr int NL = WD_NL, NT = WD_NT, NV = NL + NT, TLD = WD_LD;
   static_assert(NV == 16, "a limb's local matrix fills one 16-lane row");
-  const int grp = lane_in >> 4, lane = lane_in & 15;
+  int lane_in = fresh_lane(lane_in0);
+  int grp = lane_in >> 4, lane = lane_in & 15;
   const double* H = sm + LD.H;
   double* xs = sm + LD.x;
   const double* los = sm + LD.lo;
@@ -330,12 +337,12 @@ __device__ __forceinline__ int solve_rows(DimsRef D, double* sm, const char* __r
   unsigned long long* vset = reinterpret_cast<unsigned long long*>(sm + LD.vset);   // {to_lower, to_upper, release, flags} x 2
   const int* tree = img_at<int>(img, IM.tree);
 
-  const bool is_limb = lane < NL, is_trunk = !is_limb;
-  const int a = lane, t = lane - NL;
+  bool is_limb = lane < NL, is_trunk = !is_limb;
+  int a = lane, t = lane - NL;
   const int dof = tree[lane_in];
-  const bool row = dof >= 0;                                  // this lane holds a real row
-  const bool own = row && (is_limb || grp == 0);              // ... and reports the variable's violations
-  const int me = is_limb ? lane_in : lane;                    // the variable's bit in the bound sets
+  bool row = dof >= 0;                                        // this lane holds a real row
+  bool own = row && (is_limb || grp == 0);                    // ... and reports the variable's violations
+  int me = is_limb ? lane_in : lane;                          // the variable's bit in the bound sets
   const double lo = row ? los[dof] : 0.0, hi = row ? his[dof] : 0.0;
   const double ci = row ? (sm + LD.c)[dof] : 0.0;
   const double* LMrow = H + 7 * lane_in;                      // D_g row a (limb lanes) / B_g row t (trunk lanes)
@@ -347,6 +354,15 @@ __device__ __forceinline__ int solve_rows(DimsRef D, double* sm, const char* __r
   int pcount = 3, ninf_best = 65;
   for (int it = 0; it < 100; it++) {
     PROF_BEGIN(pr);
+    // (a round starts from a fresh copy of the lane id: its lane predicates are recomputed here -- one v_cmp each --
+    //  instead of living in spilled scalar-register pairs across the whole frame loop)
+    lane_in = fresh_lane(lane_in0);
+    grp = lane_in >> 4; lane = lane_in & 15;
+    is_limb = lane < NL; is_trunk = !is_limb;
+    a = lane; t = lane - NL;
+    row = dof >= 0;
+    own = row && (is_limb || grp == 0);
+    me = is_limb ? lane_in : lane;
     const unsigned long long fixedm = bs.lower | bs.upper;
     const unsigned long long gone = fixedm | absent;          // columns that are the identity in this round
     const unsigned cf = (unsigned)(gone >> (16 * grp)) & 0x7Fu;   // limb columns of this group
@@ -627,6 +643,7 @@ __device__ __forceinline__ int solve_rows(DimsRef D, double* sm, const char* __r
 // (sin, cos) of every hinge's half angle for a configuration that did not come out of integrate_wide (q0)
 template <class DimsRef>
 __device__ __forceinline__ void hinge_sincos(DimsRef D, double* sm, int lane) {
+  lane = fresh_lane(lane);     // (lane predicates of this phase are computed here and die with it: gmr_device_math.h)
   if (lane >= 6 && lane < D.nv) {
     double s, c;
     sincos_small(0.5 * (sm + LD.q)[7 + lane - 6], &s, &c);
@@ -639,6 +656,7 @@ __device__ __forceinline__ void hinge_sincos(DimsRef D, double* sm, int lane) {
 template <class DimsRef>
 __device__ __forceinline__ void integrate_wide(DimsRef D, double* sm, double dt, int lane, Prof& pr) {
   PROF_BEGIN(pr);
+  lane = fresh_lane(lane);     // (lane predicates of this phase are computed here and die with it: gmr_device_math.h)
   double* q = sm + LD.q;
   const double* dq = sm + LD.x;
   const bool base = lane == 0, hinge = lane >= 6 && lane < D.nv;
@@ -673,6 +691,7 @@ template <class DimsRef>
 __device__ __forceinline__ void preprocess_wide(DimsRef D, double* sm, const char* __restrict__ img, int human_root,
                                                 double ground_offset, int flags, int lane, Prof& pr) {
   PROF_BEGIN(pr);
+  lane = fresh_lane(lane);     // (lane predicates of this phase are computed here and die with it: gmr_device_math.h)
   const double* raw = sm + LD.raw;
   double* tgt = sm + LD.tgt;
   double z = INFINITY;
