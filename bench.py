@@ -48,6 +48,33 @@ from general_motion_retargeting_amd.models import load_ik_config, load_robot  # 
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (spec sheet)
+def kernel_sources_sha256() -> str:
+    """Hash of every kernel / layout source of libgmrhip.so: profiles/traffic.json carries the hash it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "general_motion_retargeting_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".inc")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
+
+
+def _traffic_profile():
+    """profiles/traffic.json if it was measured on THESE kernel sources, else (None, why)."""
+    prof = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(prof):
+        return None, "profiles/traffic.json missing"
+    try:
+        with open(prof) as f:
+            pj = json.load(f)
+    except Exception as e:  # noqa: BLE001
+        return None, f"profiles/traffic.json unreadable: {e}"
+    if pj.get("kernel_sources_sha256") != kernel_sources_sha256():
+        return None, "stale: profiles/traffic.json was measured on other kernel sources than HEAD's (re-run tools/profile_round3.sh + tools/publish_profiles.py)"
+    return pj, None
+
+
 def _wide_roofline(robot, frames, solves_per_frame, seconds):
     """HBM and FP64-VALU fractions of the throughput kernel over one step of the 1M-frame leg (wall clock of the step:
     queue initialisation + kernel), same accounting as the headline's `roofline`."""
@@ -56,9 +83,26 @@ def _wide_roofline(robot, frames, solves_per_frame, seconds):
     gbs = BYTES_PER_FRAME.get(robot, 1360) * frames / seconds / 1e9
     return {"kernel": "ik_wide_kernel (queued dispatch)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_frame": BYTES_PER_FRAME.get(robot, 1360),
-            "fp64_valu": {"achieved_tflops": flops / seconds / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                          "frac": flops / seconds / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                          "flops_model": "SURVEY.md 8(d) dense accounting, measured solve counts"}}
+            "fp64_valu": dict({"achieved_tflops": flops / seconds / 1e12, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                               "frac": flops / seconds / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                               "flops_model": "SURVEY.md 8(d) dense accounting, measured solve counts"},
+                              **_executed_frac(nsolve, seconds))}
+
+
+def _executed_frac(nsolve, seconds):
+    """FP64 flop the throughput kernel EXECUTES (counter file: FMA / MUL / ADD / TRANS wave-instructions per solve x the mean
+    active-lane fraction) x the solves measured here -- beside the dense-model `frac`, which counts flop a sparse kernel
+    rightly never performs."""
+    pj, why = _traffic_profile()
+    w = (pj or {}).get("wide")
+    if not w:
+        return {"executed_frac": None, "executed_note": why or "no throughput-kernel counters in profiles/traffic.json"}
+    tf = w["executed_fp64_flop_per_solve"] * nsolve / seconds / 1e12
+    return {"executed_tflops": tf, "executed_frac": tf / FP64_VALU_PEAK_TFLOPS,
+            "executed_frac_all_lanes_live": w["executed_fp64_flop_per_solve_all_lanes_live"] * nsolve / seconds / 1e12 / FP64_VALU_PEAK_TFLOPS,
+            "mean_active_lane_fraction": w.get("mean_active_lane_fraction_of_valu"), "valu_per_solve": w.get("valu_per_solve"),
+            "lds_bank_conflict_share": w.get("lds_bank_conflict_share"),
+            "executed_source": "profiles/traffic.json `wide` (rocprofv3 PMC, same kernel sources as HEAD) x the solve count of this run"}
 
 
 # SURVEY.md 8(d), G1: algorithmic bytes and flops
@@ -428,16 +472,12 @@ def main():
                 "flops_model": "SURVEY.md 8(d) dense accounting, measured solve counts",
             },
         }
-        prof = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(prof):
-            try:
-                with open(prof) as f:
-                    pj = json.load(f)
-                if pj.get("streams") == S and pj.get("frames") == T:
-                    roofline["traffic"] = pj.get("hbm_bytes_per_launch")
-                    roofline["traffic_source"] = pj.get("source")
-            except Exception:
-                pass
+        pj, why = _traffic_profile()
+        if pj is not None and pj.get("streams") == S and pj.get("frames") == T:
+            roofline["traffic"] = pj.get("hbm_bytes_per_launch")
+            roofline["traffic_source"] = pj.get("source")
+        else:
+            roofline["traffic_note"] = why or "profiles/traffic.json holds another workload"
         weak_cfg = {
             "workload": f"10k-frame synthetic SMPL-X batch -> Unitree G1 (29-DoF): S={S} streams x T={T} "
                         f"frames per GPU, two-stage IK, time loop on device (BASELINE.json configs[1])",

@@ -44,7 +44,8 @@ def needs_build() -> bool:
 
 def _object(src: str, defines, force: bool, verbose: bool) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    defines = PER_SOURCE_FLAGS.get(src, []) + list(defines)
+    per_source = [] if os.environ.get("GMR_BUILD_NO_PER_SOURCE_FLAGS") else PER_SOURCE_FLAGS.get(src, [])   # (A/B builds)
+    defines = per_source + list(defines)
     tag = hashlib.sha1(" ".join(FLAGS + defines).encode()).hexdigest()[:10]
     obj = os.path.join(OBJ, f"{os.path.splitext(src)[0]}.{tag}.o")
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS]

@@ -435,13 +435,10 @@ __device__ __forceinline__ int solve_rows(DimsRef D, double* sm, const char* __r
       }
       const double yp = row_bcast_d(b, p) * dinv;            // row p keeps its unscaled b (l = 0 there): scaled after the loop
       b = fma(-l, yp, b);
-#ifdef GMR_WIDE_MFMA_SCHUR
 #pragma unroll
-      for (int k = (p + 1 < NL ? p + 2 : p + 1); k < NL; k++) r[k] = fma(-l, row_bcast_d(l, k), r[k]);   // limb columns only
-#else
-#pragma unroll
+      // (the Schur products -Y_g Y_g^T on the matrix cores -- v_mfma_f64_16x16x4 with A = B^T = Y_g -- were measured twice:
+      //  -3.5 % in round 2, -1.7 % in round 3 at 158 instead of 229 registers)
       for (int k = (p + 1 < NL ? p + 2 : p + 1); k < NV; k++) r[k] = fma(-l, row_bcast_d(l, k), r[k]);
-#endif
       dinv = dinv_next;
     }
     if (is_limb) b *= mydinv;                                // y_p = b_p / sqrt(d_p): the value every later row was given
@@ -451,44 +448,11 @@ __device__ __forceinline__ int solve_rows(DimsRef D, double* sm, const char* __r
 #pragma unroll
     for (int m = 0; m < NL; m++) Lscr[lane * TLD + m] = r[m];
     if (is_trunk) rpart[grp * NT + t] = b;
-#ifdef GMR_WIDE_MFMA_SCHUR
-    // Measured alternative: the Schur contributions -Y_g Y_g^T (four 9 x 7 by 7 x 9 products) on
-    // the matrix cores.  v_mfma_f64_16x16x4_f64 wants A[i][k] in lane i + 16 k and B[k][j] in lane j + 16 k: with
-    // A = Y_g and B = Y_g^T both operands are the SAME register, filled from the transposes just parked in LDS
-    // (lane l reads Y_g[l & 15][4 s + (l >> 4)] for K-step s); D[row = (l >> 4) + 4 reg][col = l & 15] goes straight to
-    // the exchange buffer.  8 LDS reads + 8 MFMAs instead of 63 (row broadcast + FMA) column updates.
-    {
-      typedef double d4v __attribute__((ext_vector_type(4)));
-      wsync();
-      const int mi = lane_in & 15, mk = lane_in >> 4;
-      d4v acc[4];
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const double* Lg = sm + LD.lscr + g * 16 * TLD + mi * TLD;
-        const double a0 = Lg[mk];                                   // Y_g[mi][mk]
-        const double a1 = (4 + mk < NL) ? Lg[4 + mk] : 0.0;         // Y_g[mi][4 + mk] (column 7 does not exist)
-        d4v c = {0.0, 0.0, 0.0, 0.0};
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, c, 0, 0, 0);
-        acc[g] = c;
-      }
-      if (mi >= NL) {
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-#pragma unroll
-          for (int ri = 0; ri < 4; ri++) {
-            const int rowi = mk + 4 * ri;
-            if (rowi >= NL && mi <= rowi) Spart[g * WD_TRI + ((rowi - NL) * (rowi - NL + 1)) / 2 + (mi - NL)] = -acc[g][ri];
-          }
-      }
-    }
-#else
     if (is_trunk) {                                           // row t of the contribution: columns u <= t only are ever read
       double* sp = Spart + grp * WD_TRI + (t * (t + 1)) / 2;
 #pragma unroll
       for (int u = 0; u < NT; u++) if (u <= t) sp[u] = r[NL + u];
     }
-#endif
     unsigned long long* vcur = vset + 4 * (it & 1);
     if (lane == 0 && bad) atomicOr(&vcur[3], 1ull);
     wsync();                                                                                 // B1
