@@ -842,3 +842,80 @@ def test_group_launch_device_pointers_and_pinned_pipeline(hip):
     for (sol, S, T, *_), b, a in zip(dev, bufs, ref):
         assert np.array_equal(b[2].to_host((S, T, sol.nq), np.float64), a[0])
         assert np.array_equal(b[3].to_host((S, T, 2), np.int32), a[1]) and not b[4].to_host((S,), np.int32).any()
+
+
+@pytest.mark.gpu
+def test_full_size_config_lafan1_shape_properties(hip, oracle):
+    """BASELINE.json configs[2] at full size on one GPU: 77 ragged streams, ~496 k frames (bvh -> G1, the LAFAN1-shaped
+    stand-in of bench.py's leg).  Status, iteration counts, joint limits, unit root quaternions, zeros beyond a clip's
+    length; a sample of clips frame by frame against the oracle; batch invariance (a clip alone == the clip in the batch)."""
+    import os
+    from general_motion_retargeting_amd import GeneralMotionRetargeting, synth
+    rng = np.random.default_rng(3)
+    lens = rng.integers(3000, 9500, size=77)
+    lens = (lens * (496000 / lens.sum())).astype(np.int32)
+    g = GeneralMotionRetargeting("bvh", "unitree_g1", actual_human_height=1.75)
+    T = int(lens.max())
+    base_h, _ = synth.make_streams(g.model, g._tables, 77, 600, seed=30, workers=4)
+    idx = np.arange(T) % 1198
+    idx = np.where(idx < 600, idx, 1198 - idx)
+    human = np.ascontiguousarray(base_h[:, idx])
+    q, ns, st = g.retarget_streams(human, lens=lens)
+    assert (st == 0).all() and int(lens.sum()) > 490000
+    m = g.model
+    for s in range(77):
+        n = int(lens[s])
+        assert (ns[s, :n] >= 1).all() and (ns[s, :n] <= 11).all() and not ns[s, n:].any() and not q[s, n:].any()
+        assert np.abs(np.linalg.norm(q[s, :n, 3:7], axis=-1) - 1).max() < 1e-13
+        th = q[s, :n, 7:]
+        lim = m.limited > 0
+        assert (th[:, lim] >= m.range_lo[lim] - 1e-12).all() and (th[:, lim] <= m.range_hi[lim] + 1e-12).all()
+    mb, ts = g._model_blob, g._taskset_blob
+    q0 = np.broadcast_to(m.qpos0, (77, m.nq)).copy()
+    for s in (0, 38, int(np.argmax(lens))):                       # the oracle on whole clips (a few seconds each)
+        n = min(int(lens[s]), 1500)
+        q_o, ns_o, _ = oracle.retarget_streams(mb, ts, q0[s:s + 1], human[s:s + 1, :n], nthreads=os.cpu_count() or 1)
+        assert np.array_equal(ns[s, :n], ns_o[0])
+        joint, pos, rot = _compare(q[s, :n], q_o[0])
+        assert joint <= 1e-8 and pos <= 1e-8 and rot <= 1e-8, (s, joint, pos, rot)
+    q1, ns1, st1 = g.retarget_streams(human[5:6, : lens[5]])      # one clip by itself: the same bits
+    assert np.array_equal(q1[0], q[5, : lens[5]]) and np.array_equal(ns1[0], ns[5, : lens[5]])
+
+
+@pytest.mark.gpu
+def test_full_size_config_mixed_1m_properties(hip, oracle):
+    """BASELINE.json configs[3] at full size on one GPU: 1 048 576 frames = 4 096 streams x 256 frames round-robin over
+    the six robots, ONE group launch through pinned host buffers.  Status, iteration counts, limits per robot; the oracle
+    on a sample of streams of every robot; batch invariance against every robot launched by itself."""
+    import os
+    from general_motion_retargeting_amd import GeneralMotionRetargeting, synth
+    T, S_total = 256, 4096
+    jobs, gm = [], []
+    for r, robot in enumerate(SIX_ROBOTS):
+        g = GeneralMotionRetargeting("smplx", robot)
+        S = len(range(r, S_total, 6))
+        bh, _ = synth.make_streams(g.model, g._tables, 64, T, seed=1 + 1000 * r, workers=4)
+        human = hip.pinned_empty((S, T, bh.shape[2], 7))
+        for s0 in range(0, S, 64):
+            human[s0:s0 + 64] = bh[: S - s0]
+        q0 = np.broadcast_to(g.model.qpos0, (S, g.model.nq)).copy()
+        jobs.append({"solver": g.hip_solver, "human": human, "q0": q0})
+        gm.append(g)
+    out = hip.retarget_group(jobs, 0, 0, outs=hip.group_outputs(jobs))
+    assert sum(j["human"].shape[0] for j in jobs) * T == 1 << 20
+    for g, j, (q, ns, st) in zip(gm, jobs, out):
+        m = g.model
+        assert (st == 0).all() and (ns >= 1).all() and (ns <= 11).all()
+        assert np.abs(np.linalg.norm(q[..., 3:7], axis=-1) - 1).max() < 1e-13
+        lim = m.limited > 0
+        th = q[..., 7:]
+        assert (th[..., lim] >= m.range_lo[lim] - 1e-12).all() and (th[..., lim] <= m.range_hi[lim] + 1e-12).all()
+        assert np.array_equal(q[64:128], q[:64])                   # the tiled motifs: equal inputs, equal bits, wherever they ran
+        for s in (3, 40):
+            q_o, ns_o, _ = oracle.retarget_streams(g._model_blob, g._taskset_blob, j["q0"][s:s + 1], np.asarray(j["human"][s:s + 1]),
+                                                   nthreads=os.cpu_count() or 1)
+            assert np.array_equal(ns[s], ns_o[0])
+            joint, pos, rot = _compare(q[s], q_o[0])
+            assert joint <= 1e-8 and pos <= 1e-8 and rot <= 1e-8, (g.tgt_robot if hasattr(g, "tgt_robot") else "", joint, pos, rot)
+        alone = j["solver"].retarget_streams(j["q0"][:96], np.asarray(j["human"][:96]))      # the robot by itself, another launch shape
+        assert np.array_equal(alone[1], ns[:96]) and np.abs(alone[0] - q[:96]).max() <= 1e-9
