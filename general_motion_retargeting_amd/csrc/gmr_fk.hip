@@ -355,6 +355,7 @@ __global__ __launch_bounds__(64 * FK_MAX_WAVES) void fk_split_kernel(const FkTre
     const int j = (int)(cur.meta >> 24);
     const int src = (int)((cur.meta >> 8) & 255u) - 1, dst = (int)((cur.meta >> 16) & 255u) - 1;
     const bool own = cur.meta & 16u;
+    if (cur.meta & 32u) __syncthreads();           // shared trunk: the transforms this wavefront continues from are parked (fk_build_split)
     const float ang = ang_nxt;                     // parked angle of this body, read while the previous body was walked
     if (cur.next_park >> 31) ang_nxt = *((cur.next_park & 0x40000000u) ? xtra + 64 * (cur.next_park & 0xffffu) : orow + (cur.next_park & 0x3fffffffu));
     float ppx = cpx, ppy = cpy, ppz = cpz;
@@ -375,6 +376,10 @@ __global__ __launch_bounds__(64 * FK_MAX_WAVES) void fk_split_kernel(const FkTre
       float* sl = stk + dst * 7 * 64;
       sl[0] = px; sl[64] = py; sl[128] = pz; sl[192] = rot.x; sl[256] = rot.y; sl[320] = rot.z; sl[384] = rot.w;
     }
+    if (const unsigned xd = (cur.meta >> 6) & 3u) {  // a parent other wavefronts continue from after the barrier
+      float* sl = stk + (xd - 1) * 7 * 64;
+      sl[0] = px; sl[64] = py; sl[128] = pz; sl[192] = rot.x; sl[256] = rot.y; sl[320] = rot.z; sl[384] = rot.w;
+    }
     if (own) {
       float* o = orow + 3 * j;
       o[0] = px; o[1] = py; o[2] = pz;
@@ -382,6 +387,7 @@ __global__ __launch_bounds__(64 * FK_MAX_WAVES) void fk_split_kernel(const FkTre
       if (on) zmin = fminf(zmin, pz);
     }
   }
+  if (tree->wave_tail_barrier[wave]) __syncthreads();   // (a wavefront whose list ended before the block's mid-walk barrier)
   __syncthreads();
 #ifdef GMR_FK_EXP_NOFLUSH
   if (B > 0) { if (zmin == 12345.f) body_pos[0] = outb[threadIdx.x]; return; }

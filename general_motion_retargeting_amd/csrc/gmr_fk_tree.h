@@ -16,6 +16,8 @@ constexpr int FK_MAX_WAVES = 4;
 struct FkBodyRec {
   float t[3];                 // local translation
   uint32_t meta;              // [0] has a hinge, [15:8] load slot + 1 (0: parent = previous body), [23:16] save slot + 1, [31:24] parent
+                              // split walk: [4] this wavefront stores the body, [5] workgroup barrier BEFORE this body (shared
+                              // trunk), [7:6] also save the transform in block-wide LDS slot ([7:6] - 1) for other wavefronts
   float r[4];                 // local rotation xyzw, un-normalised
   double axis[3];             // normalised hinge axis (float64)
   int32_t dof_idx;            // first dof of the joint or -1
@@ -51,6 +53,9 @@ struct FkTree {
   // extra column [index][lane] behind the staging area (nextra columns per block); 0xffffffff ends the list
   uint32_t wave_park[FK_MAX_WAVES][32];
   int nextra;
+  // shared trunk (fk_build_split): the wavefront executes the block's one mid-walk barrier after its list instead of
+  // before one of its bodies (record flag, meta bit 5)
+  int wave_tail_barrier[FK_MAX_WAVES];
 };
 
 // Partition of the tree for the split walk (host side, gmr_fk_create).  `parent[b] < b`.  Returns the number of
@@ -138,13 +143,64 @@ inline const char* fk_build_split(FkTree& t, const int32_t* parent, int maxw) {
   for (int b = 0; b < nbody; b++) par[b] = b == 0 ? -1 : parent[b];
   t.nwave = nbody >= 8 ? fk_split_tree(nbody, par, maxw, lists, nlist) : 1;
   if (t.nwave == 1) { nlist[0] = nbody; for (int b = 0; b < nbody; b++) lists[0][b] = b; }
+  // Shared trunk.  fk_split_tree lets every wavefront recompute the chain of ancestors its subtrees hang from (for the G1:
+  // the three waist bodies, walked by three wavefronts).  When all such shared bodies belong to ONE wavefront w0 and open
+  // its list, they are walked by w0 alone: w0 parks the transforms other wavefronts need as parents in block-wide LDS slots,
+  // the block meets at ONE barrier, and the others continue from those slots (38 + 2 instead of 47 body evaluations per
+  // frame for the G1).  A wavefront without such a dependency places the barrier where w0 is expected to arrive.
+  int shared_slot[FK_MAX_BODIES], barrier_at[FK_MAX_WAVES], extra_dst[FK_MAX_BODIES];
+  for (int b = 0; b < nbody; b++) { shared_slot[b] = -1; extra_dst[b] = 0; }
+  for (int w = 0; w < FK_MAX_WAVES; w++) { barrier_at[w] = -1; t.wave_tail_barrier[w] = 0; }
+  int nshared = 0, share_owner = -1;
+  if (t.nwave > 1 && !getenv("GMR_FK_NO_SHARE")) {
+    int first[FK_MAX_BODIES], count[FK_MAX_BODIES];
+    for (int b = 0; b < nbody; b++) { first[b] = -1; count[b] = 0; }
+    for (int w = 0; w < t.nwave; w++) for (int i = 0; i < nlist[w]; i++) { const int b = lists[w][i]; if (first[b] < 0) first[b] = w; count[b]++; }
+    int A[FK_MAX_BODIES], nA = 0, w0 = -1;
+    bool ok = true;
+    for (int b = 1; b < nbody; b++) if (count[b] > 1) { if (w0 < 0) w0 = first[b]; ok = ok && first[b] == w0; A[nA++] = b; }
+    ok = ok && nA > 0 && w0 >= 0 && nlist[w0] > nA;
+    for (int i = 0; ok && i < nA; i++) ok = lists[w0][1 + i] == A[i];            // the shared bodies open w0's list, in order
+    bool inA[FK_MAX_BODIES] = {false};
+    for (int i = 0; i < nA; i++) inA[A[i]] = true;
+    // the transforms other wavefronts need as parents: at most 3 block-wide slots (two bits in the record)
+    int need[FK_MAX_BODIES], nneed = 0;
+    for (int w = 0; ok && w < t.nwave; w++) {
+      if (w == w0) continue;
+      for (int i = 0; i < nlist[w]; i++) {
+        const int b = lists[w][i];
+        if (b == 0 || inA[b]) continue;
+        const int p = par[b];
+        if (inA[p]) { bool seen = false; for (int k = 0; k < nneed; k++) seen = seen || need[k] == p; if (!seen) need[nneed++] = p; }
+      }
+    }
+    ok = ok && nneed >= 1 && nneed <= 3;
+    if (ok) {
+      share_owner = w0;
+      for (int k = 0; k < nneed; k++) { shared_slot[need[k]] = k; extra_dst[need[k]] = k + 1; }
+      nshared = nneed;
+      for (int w = 0; w < t.nwave; w++) {
+        if (w == w0) { barrier_at[w] = 1 + nA; continue; }
+        int m = 0;
+        for (int i = 0; i < nlist[w]; i++) if (!inA[lists[w][i]]) lists[w][m++] = lists[w][i];      // drop the shared bodies
+        nlist[w] = m;
+        int at = -1;
+        for (int i = 1; i < m && at < 0; i++) if (inA[par[lists[w][i]]]) at = i;                   // first body that hangs from the shared trunk
+        // ... but not later than w0 is expected to arrive (everybody waits for the last one): the barrier may come
+        // before the first dependent body, never after it
+        const int when = 1 + nA < m ? 1 + nA : m;
+        barrier_at[w] = (at >= 0 && at < when) ? at : when;
+      }
+    }
+  }
   bool owned[FK_MAX_BODIES] = {false};
-  int nrec = 0, nslot = 0;
+  int nrec = 0, nslot = nshared;
   for (int w = 0; w < t.nwave; w++) {
     t.wave_start[w] = nrec;
     const int n = nlist[w];
     int slot_of[FK_MAX_BODIES];
-    for (int b = 0; b < nbody; b++) slot_of[b] = -1;
+    for (int b = 0; b < nbody; b++) slot_of[b] = (share_owner >= 0 && w != share_owner) ? shared_slot[b] : -1;
+    if (share_owner >= 0 && barrier_at[w] >= n) t.wave_tail_barrier[w] = 1;
     bool spare_used = false;                    // a wavefront's first parked parent lives in registers (slot code 254)
     for (int i = 1; i < n; i++) {               // a parent that is not the body walked just before is reloaded from a slot
       const int p = par[lists[w][i]];
@@ -160,7 +216,11 @@ inline const char* fk_build_split(FkTree& t, const int32_t* parent, int maxw) {
       const int src = (i == 0 || lists[w][i - 1] == p) ? -1 : slot_of[p];
       const bool own = !owned[b];
       owned[b] = true;
-      r.meta = (r.meta & 0xFu) | (own ? 16u : 0u) | ((uint32_t)(src + 1) << 8) | ((uint32_t)(slot_of[b] + 1) << 16) | ((uint32_t)b << 24);
+      // (a shared parent seeded slot_of[] of the other wavefronts: it is a LOAD slot there, never a save slot)
+      const int dst = (share_owner >= 0 && w != share_owner && shared_slot[b] >= 0) ? -1 : slot_of[b];
+      r.meta = (r.meta & 0xFu) | (own ? 16u : 0u) | ((uint32_t)(src + 1) << 8) | ((uint32_t)(dst + 1) << 16) | ((uint32_t)b << 24);
+      if (share_owner >= 0 && i == barrier_at[w]) r.meta |= 32u;
+      if (w == share_owner) r.meta |= (uint32_t)extra_dst[b] << 6;
       if (nrec >= 2 * FK_MAX_BODIES) return "too many records";
       t.wrec[nrec++] = r;
     }
