@@ -78,6 +78,9 @@ _SIGS = {
                                       C.c_void_p, C.c_void_p]),
     "gmr_smplx_align": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_void_p]),
+    "gmr_smplx_compact_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int)]),
+    "gmr_smplx_align_compact_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]),
     "gmr_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     "gmr_comm_destroy": (C.c_int, [C.c_void_p]),
     "gmr_comm_rank": (C.c_int, [C.c_void_p]),
@@ -539,6 +542,19 @@ class SmplxHandle:
         check(lib().gmr_smplx_align(self.handle, N, int(joints.shape[1]), _ptr(full_pose), _ptr(joints), nout, _ptr(tt),
                                     _ptr(out)))
         return out
+
+    def compact_layout(self):
+        """(pose_joints, row_joints): the joints whose poses / positions the alignment reads, in the order of the compact
+        inputs of :meth:`align_compact_dev`."""
+        pj = np.zeros(self.J, dtype=np.int32)
+        rj = np.zeros(self.J, dtype=np.int32)
+        npose, nrow = C.c_int(), C.c_int()
+        check(lib().gmr_smplx_compact_layout(self.handle, _ptr(pj), C.byref(npose), _ptr(rj), C.byref(nrow)))
+        return pj[: npose.value].copy(), rj[: nrow.value].copy()
+
+    def align_compact_dev(self, N, d_pose_c, d_joints_c, nout, d_target_time, d_out, stream=None):
+        check(lib().gmr_smplx_align_compact_dev(self.handle, int(N), _d(d_pose_c), _d(d_joints_c), int(nout), _d(d_target_time),
+                                                _d(d_out), _s(stream)))
 
     def align_dev(self, N, jstride, d_full_pose, d_joints, nout, d_target_time, d_out, stream=None):
         check(lib().gmr_smplx_align_dev(self.handle, int(N), int(jstride), _d(d_full_pose), _d(d_joints), int(nout),

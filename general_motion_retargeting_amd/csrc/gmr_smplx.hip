@@ -103,7 +103,10 @@ __device__ __forceinline__ q4 sx_slerp_local(q4 q1, q4 q2, double t) {
 #pragma clang fp contract(off)
 
 // out[Nout][nrow][7]: pos xyz, quat wxyz.  ALIGN: target_time[Nout] (np.linspace(0, N-1, Nout)); else Nout == N.
-template <bool ALIGN>
+// COMPACT: the inputs hold only what the kernel reads -- full_pose[N][P.n][3] in the order of the program's steps (the
+// ancestor closure of the selection), joints[N][P.nrow][3] in output-row order -- so that every fetched line is used:
+// of a 660-byte SMPL-X pose row the walk needs 20 of 55 joints (round-2 counters: 6.3 x the algorithmic traffic).
+template <bool ALIGN, bool COMPACT>
 __global__ __launch_bounds__(SX_BLOCK) void smplx_align_kernel(SmplxProg P, int N, int jstride,
                                                                const float* __restrict__ full_pose,
                                                                const float* __restrict__ joints, int Nout,
@@ -125,13 +128,14 @@ __global__ __launch_bounds__(SX_BLOCK) void smplx_align_kernel(SmplxProg P, int 
     ss = min(max(ss, 1), N - 1);
     lo = ss - 1; hi = ss;
   }
-  const float* p1 = full_pose + (size_t)idx1 * P.J * 3;
-  const float* p2 = full_pose + (size_t)idx2 * P.J * 3;
-  const float* jl = joints + (size_t)lo * jstride * 3;
-  const float* jh = joints + (size_t)hi * jstride * 3;
+  const int prow = COMPACT ? P.n : P.J, jrow = COMPACT ? P.nrow : jstride;
+  const float* p1 = full_pose + (size_t)idx1 * prow * 3;
+  const float* p2 = full_pose + (size_t)idx2 * prow * 3;
+  const float* jl = joints + (size_t)lo * jrow * 3;
+  const float* jh = joints + (size_t)hi * jrow * 3;
   double* orow = out + (size_t)o * P.nrow * 7;
   for (int k = 0; k < P.n; k++) {
-    const int j = P.joint[k], d = P.depth[k];
+    const int j = COMPACT ? k : P.joint[k], d = P.depth[k];
     q4 ql;
     if (ALIGN) {
       q4 qa = sx_from_rotvec((double)p1[3 * j], (double)p1[3 * j + 1], (double)p1[3 * j + 2]);
@@ -152,15 +156,16 @@ __global__ __launch_bounds__(SX_BLOCK) void smplx_align_kernel(SmplxProg P, int 
     const int r = P.row[k];
     if (r >= 0) {
       double* w = orow + r * 7;
+      const int jj = COMPACT ? r : j;                                 // (compact joints: one row per output row)
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         if (ALIGN) {
-          const float ylo = jl[3 * j + c], yhi = jh[3 * j + c];
+          const float ylo = jl[3 * jj + c], yhi = jh[3 * jj + c];
           const float df = yhi - ylo;                                  // float32 difference (interp1d on a float32 y)
           const double slope = (double)df / (double)(hi - lo);
           w[c] = slope * (t - (double)lo) + (double)ylo;
         } else {
-          w[c] = (double)jl[3 * j + c];
+          w[c] = (double)jl[3 * jj + c];
         }
       }
       w[3] = qg.w; w[4] = qg.x; w[5] = qg.y; w[6] = qg.z;
@@ -308,8 +313,10 @@ int gmr_smplx_create(int J, const int32_t* parents, int nsel, const int32_t* sel
   if (lds_joints > 160 * 1024 - 1024) { delete h; return gmr_fail(GMR_ERR_ARG, "gmr_smplx_create: tree too deep (%d levels)", h->all.max_depth); }
   hipError_t e = hipSuccess;
   if (lds_align > 48 * 1024) {
-    e = hipFuncSetAttribute((const void*)gmr::smplx_align_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_align);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gmr::smplx_align_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_align);
+    e = hipFuncSetAttribute((const void*)gmr::smplx_align_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_align);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gmr::smplx_align_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_align);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gmr::smplx_align_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_align);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gmr::smplx_align_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_align);
   }
   if (e == hipSuccess && lds_joints > 48 * 1024)
     e = hipFuncSetAttribute((const void*)gmr::smplx_joints_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_joints);
@@ -340,9 +347,9 @@ int gmr_smplx_joints_dev(gmr_smplx_t* h, int N, const double* d_j_rest, const fl
   return GMR_OK;
 }
 
-int gmr_smplx_align_dev(gmr_smplx_t* h, int N, int jstride, const float* d_full_pose, const float* d_joints, int Nout,
-                        const double* d_target_time, double* d_out, void* stream) {
-  if (!h || N < 1 || Nout < 0 || jstride < h->J || !d_full_pose || !d_joints || !d_out)
+static int smplx_align_launch(gmr_smplx_t* h, bool compact, int N, int jstride, const float* d_full_pose, const float* d_joints,
+                              int Nout, const double* d_target_time, double* d_out, void* stream) {
+  if (!h || N < 1 || Nout < 0 || (!compact && jstride < h->J) || !d_full_pose || !d_joints || !d_out)
     return gmr_fail(GMR_ERR_ARG, "gmr_smplx_align_dev: bad argument");
   if (!d_target_time && Nout != N) return gmr_fail(GMR_ERR_ARG, "gmr_smplx_align_dev: without target times Nout must equal N");
   if (d_target_time && N < 2) return gmr_fail(GMR_ERR_ARG, "gmr_smplx_align_dev: fps alignment needs at least two source frames");
@@ -350,15 +357,39 @@ int gmr_smplx_align_dev(gmr_smplx_t* h, int N, int jstride, const float* d_full_
   const gmr::SmplxProg& P = h->sel;
   const int lds = P.max_depth * 4 * SX_BLOCK * 8;
   dim3 grid((Nout + SX_BLOCK - 1) / SX_BLOCK), block(SX_BLOCK);
-  if (d_target_time)
-    hipLaunchKernelGGL(gmr::smplx_align_kernel<true>, grid, block, lds, (hipStream_t)stream, P, N, jstride, d_full_pose,
-                       d_joints, Nout, d_target_time, d_out);
-  else
-    hipLaunchKernelGGL(gmr::smplx_align_kernel<false>, grid, block, lds, (hipStream_t)stream, P, N, jstride, d_full_pose,
-                       d_joints, Nout, d_target_time, d_out);
+#define GMR_SX_LAUNCH(A, C)                                                                                              \
+  hipLaunchKernelGGL((gmr::smplx_align_kernel<A, C>), grid, block, lds, (hipStream_t)stream, P, N, jstride, d_full_pose, \
+                     d_joints, Nout, d_target_time, d_out)
+  if (d_target_time) { if (compact) GMR_SX_LAUNCH(true, true); else GMR_SX_LAUNCH(true, false); }
+  else { if (compact) GMR_SX_LAUNCH(false, true); else GMR_SX_LAUNCH(false, false); }
+#undef GMR_SX_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return gmr_fail(GMR_ERR_HIP, "smplx_align_kernel: %s", hipGetErrorString(e));
   return GMR_OK;
+}
+
+int gmr_smplx_align_dev(gmr_smplx_t* h, int N, int jstride, const float* d_full_pose, const float* d_joints, int Nout,
+                        const double* d_target_time, double* d_out, void* stream) {
+  return smplx_align_launch(h, false, N, jstride, d_full_pose, d_joints, Nout, d_target_time, d_out, stream);
+}
+
+// the joints the alignment reads, in the order the compact layout stores them: pose_joints[npose] = the ancestor closure of
+// the selection in walk order, row_joints[nrow] = the joint of every output row
+int gmr_smplx_compact_layout(const gmr_smplx_t* h, int32_t* pose_joints, int* npose, int32_t* row_joints, int* nrow) {
+  if (!h) return gmr_fail(GMR_ERR_ARG, "null handle");
+  const gmr::SmplxProg& P = h->sel;
+  if (npose) *npose = P.n;
+  if (nrow) *nrow = P.nrow;
+  for (int k = 0; k < P.n; k++) {
+    if (pose_joints) pose_joints[k] = P.joint[k];
+    if (row_joints && P.row[k] >= 0) row_joints[P.row[k]] = P.joint[k];
+  }
+  return GMR_OK;
+}
+
+int gmr_smplx_align_compact_dev(gmr_smplx_t* h, int N, const float* d_pose_c, const float* d_joints_c, int Nout,
+                                const double* d_target_time, double* d_out, void* stream) {
+  return smplx_align_launch(h, true, N, 0, d_pose_c, d_joints_c, Nout, d_target_time, d_out, stream);
 }
 
 // host-buffer variants: copy, launch, synchronise
@@ -389,7 +420,22 @@ int gmr_smplx_align(gmr_smplx_t* h, int N, int jstride, const float* full_pose, 
   if (!h || N < 1 || Nout < 0 || jstride < (h ? h->J : 0) || !full_pose || !joints || !out)
     return gmr_fail(GMR_ERR_ARG, "gmr_smplx_align: bad argument");
   if (Nout == 0) return GMR_OK;
-  const size_t nb_pose = (size_t)N * h->J * 3 * sizeof(float), nb_j = (size_t)N * jstride * 3 * sizeof(float);
+  // only what the walk reads crosses the bus and lies in device memory: the poses of the selection's ancestor closure, in walk
+  // order, and the joints of the output rows (for the G1's 14 bodies: 20 + 14 of 55 + 55 joints)
+  const gmr::SmplxProg& P = h->sel;
+  const size_t np = (size_t)P.n, nr = (size_t)P.nrow;
+  std::vector<float> pc((size_t)N * np * 3), jc((size_t)N * nr * 3);
+  int rowj[SX_MAX_JOINTS];
+  for (int k = 0; k < P.n; k++) if (P.row[k] >= 0) rowj[P.row[k]] = P.joint[k];
+  for (int n = 0; n < N; n++) {
+    const float* ps = full_pose + (size_t)n * h->J * 3;
+    const float* js = joints + (size_t)n * jstride * 3;
+    float* pd = pc.data() + (size_t)n * np * 3;
+    float* jd = jc.data() + (size_t)n * nr * 3;
+    for (size_t k = 0; k < np; k++) { const int j = P.joint[k]; pd[3 * k] = ps[3 * j]; pd[3 * k + 1] = ps[3 * j + 1]; pd[3 * k + 2] = ps[3 * j + 2]; }
+    for (size_t r = 0; r < nr; r++) { const int j = rowj[r]; jd[3 * r] = js[3 * j]; jd[3 * r + 1] = js[3 * j + 1]; jd[3 * r + 2] = js[3 * j + 2]; }
+  }
+  const size_t nb_pose = pc.size() * sizeof(float), nb_j = jc.size() * sizeof(float);
   const size_t nb_t = (size_t)Nout * sizeof(double), nb_out = (size_t)Nout * h->sel.nrow * 7 * sizeof(double);
   auto up = [](size_t v) { return (v + 63) / 64 * 64; };
   char* ws = nullptr;
@@ -400,11 +446,11 @@ int gmr_smplx_align(gmr_smplx_t* h, int N, int jstride, const float* full_pose, 
   double* d_t = (double*)(ws + up(nb_pose) + up(nb_j));
   double* d_o = (double*)(ws + up(nb_pose) + up(nb_j) + up(nb_t));
   int rc = GMR_OK;
-  if ((e = hipMemcpy(d_pose, full_pose, nb_pose, hipMemcpyHostToDevice)) != hipSuccess ||
-      (e = hipMemcpy(d_j, joints, nb_j, hipMemcpyHostToDevice)) != hipSuccess ||
+  if ((e = hipMemcpy(d_pose, pc.data(), nb_pose, hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(d_j, jc.data(), nb_j, hipMemcpyHostToDevice)) != hipSuccess ||
       (target_time && (e = hipMemcpy(d_t, target_time, nb_t, hipMemcpyHostToDevice)) != hipSuccess))
     rc = gmr_fail(GMR_ERR_HIP, "gmr_smplx_align: %s", hipGetErrorString(e));
-  if (rc == GMR_OK) rc = gmr_smplx_align_dev(h, N, jstride, d_pose, d_j, Nout, target_time ? d_t : nullptr, d_o, nullptr);
+  if (rc == GMR_OK) rc = gmr_smplx_align_compact_dev(h, N, d_pose, d_j, Nout, target_time ? d_t : nullptr, d_o, nullptr);
   if (rc == GMR_OK && (e = hipMemcpy(out, d_o, nb_out, hipMemcpyDeviceToHost)) != hipSuccess)
     rc = gmr_fail(GMR_ERR_HIP, "gmr_smplx_align: %s", hipGetErrorString(e));
   (void)hipFree(ws);

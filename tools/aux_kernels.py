@@ -70,6 +70,15 @@ ms = timed(lambda: hs.align_dev(N, 55, d_pose, d_j, len(tt), d_tt, d_o))
 byt = len(tt) * (2 * 12 * len(closure) + 2 * 12 * hs.rows + 8 + 56 * hs.rows)
 out["smplx_align_packed_rows"] = {"out_frames": len(tt), "ms": ms, "algorithmic_bytes": byt, "GBps": byt / ms / 1e6,
                                   "frac_of_8TBps": byt / ms / 1e6 / 8000.0}
+# the same alignment on COMPACT inputs (what the host entry point uploads): only the closure's poses, only the rows' joints
+pj, rj = hs.compact_layout()
+d_pc = _lib.DeviceBuffer.from_host(np.ascontiguousarray(pose[:, pj]))
+d_jc = _lib.DeviceBuffer.from_host(np.ascontiguousarray(jts[:, rj]))
+d_o2 = _lib.DeviceBuffer(len(tt) * hs.rows * 56)
+ms = timed(lambda: hs.align_compact_dev(N, d_pc, d_jc, len(tt), d_tt, d_o2))
+same = bool(np.array_equal(d_o.to_host((len(tt), hs.rows, 7), np.float64), d_o2.to_host((len(tt), hs.rows, 7), np.float64)))
+out["smplx_align_packed_rows_compact_inputs"] = {"out_frames": len(tt), "ms": ms, "algorithmic_bytes": byt, "GBps": byt / ms / 1e6,
+                                                 "frac_of_8TBps": byt / ms / 1e6 / 8000.0, "bit_identical_to_full_rows": same}
 hj = _lib.SmplxHandle(par)
 d_jr = _lib.DeviceBuffer.from_host(rng.normal(size=(55, 3)))
 d_tr = _lib.DeviceBuffer.from_host(rng.normal(size=(N, 3)).astype(np.float32))
