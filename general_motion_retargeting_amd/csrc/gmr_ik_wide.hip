@@ -136,13 +136,16 @@ __device__ __forceinline__ double errors_wide(double* sm, uint32_t taskw, int K,
   return sqrt(ss);
 }
 
-// (a) lane = task: M_k = -Jl^-1(e_k); returns the LM term mu.  (The three-lanes-per-task column form of the latency
-// kernel, se3_jlinv_col5, was measured here too: the same frames/s, 13 more registers -- 8 of them spilled to scratch.)
+// (a) M_k = -Jl^-1(e_k), by COLUMN on three lanes per task (lane = task + 16 j, j < 3: se3_jlinv_col5, the latency kernel's
+// form); returns the LM term mu.  (Round 2 measured this form here as "the same frames/s, 13 more registers, 8 of them in
+// scratch"; since the lane predicates are no longer parked -- 229 registers -- it fits, and the phase issues a third of the
+// instructions: 14 of 64 lanes were doing all of it.  GMR_WIDE_JLOG_ROWS restores the one-lane-per-task form.)
 __device__ __forceinline__ double jlog_wide(double* sm, const char* __restrict__ img, int stage, int K, double lm_damping,
                                             int lane, Prof& pr) {
   PROF_BEGIN(pr);
   lane = fresh_lane(lane);     // (lane predicates of this phase are computed here and die with it: gmr_device_math.h)
   double mu = 0.0;
+#ifdef GMR_WIDE_JLOG_ROWS
   if (lane < K) {
     const double* w = img_at<double>(img, IM.task[stage]) + 2 * lane;
     const double wp = w[0], wr = w[1];
@@ -165,6 +168,33 @@ __device__ __forceinline__ double jlog_wide(double* sm, const char* __restrict__
       mu += v * v;
     }
   }
+#else
+  const int k = lane & 15, j = lane >> 4;
+  if (k < K && j < 3) {
+    const double* e = sm + LD.e + 6 * k;
+    double ee[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) ee[r] = e[r];
+    const double* ax = sm + LD.eaux + 5 * k;
+    const double aux[5] = {ax[0], ax[1], ax[2], ax[3], ax[4]};
+    double Ac[3], Bc[3];
+    se3_jlinv_col5(ee, aux, j, Ac, Bc);
+    double* M = sm + LD.M + 18 * k + j;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { M[3 * i] = -Ac[i]; M[9 + 3 * i] = -Bc[i]; }
+    if (j == 0) {
+      const double* w = img_at<double>(img, IM.task[stage]) + 2 * k;
+      const double wp = w[0], wr = w[1];
+      double* wt = sm + LD.wts + 2 * k;
+      wt[0] = wp; wt[1] = wr;
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        double v = (r < 3 ? wp : wr) * ee[r];
+        mu += v * v;
+      }
+    }
+  }
+#endif
   mu = lm_damping * row0_sum(mu);
   wsync();                                             // (eaux is dead from here: the column phase overwrites it)
   PROF_END(pr, PH_JLOG);
