@@ -55,6 +55,7 @@ _SIGS = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gmr_retarget_group_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "gmr_retarget_group": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "gmr_retarget_group_window_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gmr_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "gmr_host_free": (C.c_int, [C.c_void_p]),
     "gmr_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
@@ -198,6 +199,10 @@ class DeviceBuffer:
         check(lib().gmr_stream_sync(s))
         return out
 
+    def zero(self, stream=None):
+        check(lib().gmr_memset(self.ptr, 0, self.nbytes, _s(stream)))
+        check(lib().gmr_stream_sync(_s(stream)))
+
     def free(self):
         if self.ptr:
             lib().gmr_free(self.ptr)
@@ -320,14 +325,19 @@ def retarget_group(jobs, flags: int = 0, slices: int = 0, out_pinned: bool = Fal
     return outs
 
 
-def retarget_group_dev(jobs, flags: int = 0, stream=None):
+def retarget_group_dev(jobs, flags: int = 0, stream=None, window=None):
     """``gmr_retarget_group_dev``: ``jobs`` = list of ``(solver, S, T, d_q0, d_human, d_len, d_q_out, d_nsolve, d_status)``
-    with device pointers (DeviceBuffer or raw); asynchronous on ``stream``."""
+    with device pointers (DeviceBuffer or raw); asynchronous on ``stream``.  ``window=(t_begin, t_end)``: only those frames of
+    every stream (``gmr_retarget_group_window_dev``; consecutive windows on one stream, starting at 0)."""
     arr = (Job * max(len(jobs), 1))()
     for i, (sol, S, T, d_q0, d_h, d_len, d_qo, d_ns, d_st) in enumerate(jobs):
         arr[i] = Job(sol.handle.value, int(S), int(T), _addr(d_q0), _addr(d_h), _addr(d_len), _addr(d_qo), _addr(d_ns),
                      _addr(d_st), None, None)
-    check(lib().gmr_retarget_group_dev(C.cast(arr, C.c_void_p), len(jobs), int(flags), _s(stream)))
+    if window is None:
+        check(lib().gmr_retarget_group_dev(C.cast(arr, C.c_void_p), len(jobs), int(flags), _s(stream)))
+    else:
+        check(lib().gmr_retarget_group_window_dev(C.cast(arr, C.c_void_p), len(jobs), int(flags), int(window[0]), int(window[1]),
+                                                  _s(stream)))
 
 
 class Stream:

@@ -36,6 +36,7 @@ struct gmr_wide_job_desc {       // (gmr_ik_wide.hip)
   double* d_q_out; int32_t* d_nsolve; int32_t* d_status; double* d_tgt_out; double* d_err_out;
 };
 extern "C" hipError_t gmr_launch_ik_wide_group(const gmr_wide_job_desc*, int, int, hipStream_t, unsigned long long*, void*);
+extern "C" hipError_t gmr_launch_ik_wide_window(const gmr_wide_job_desc*, int, int, hipStream_t, unsigned long long*, void*, int, int);
 extern "C" void* gmr_ik_wide_pool_create();
 extern "C" void gmr_ik_wide_pool_destroy(void*);
 extern "C" void gmr_ik_wide_pool_set_chunk(void*, int);
@@ -388,6 +389,158 @@ int gmr_retarget_group_dev(const gmr_job_t* jobs, int njobs, int flags, void* st
   return flush();
 }
 
+// One WINDOW of every stream's frames: [t_begin, t_end).  The windows of a batch must be launched in order on ONE stream,
+// starting at t_begin = 0; the per-stream state between them (QP bound sets, status) stays in the first job's workspace of
+// that stream; q continues from the previous window's last q_out row.  Only batches that take the throughput shape as a
+// whole (every job's robot decomposes, more than 300 streams, no solver forced to four wavefronts) can be windowed.
+static bool group_is_windowable(const gmr_job_t* jobs, int njobs) {
+  long long total = 0;
+  int n = 0;
+  for (int j = 0; j < njobs; j++) if (jobs[j].S > 0 && jobs[j].T > 0) { total += jobs[j].S; n++; }
+  if (n == 0 || n > 8) return false;
+  for (int j = 0; j < njobs; j++)
+    if (jobs[j].S > 0 && jobs[j].T > 0 && !job_takes_wide_shape(jobs[j].solver, total)) return false;
+  return true;
+}
+
+int gmr_retarget_group_window_dev(const gmr_job_t* jobs, int njobs, int flags, int t_begin, int t_end, void* stream) {
+  if (njobs < 0 || (njobs > 0 && !jobs)) return fail(GMR_ERR_ARG, "bad job list");
+  if (t_begin < 0 || t_end <= t_begin) return fail(GMR_ERR_ARG, "bad window [%d, %d)", t_begin, t_end);
+  for (int j = 0; j < njobs; j++) {
+    const gmr_job_t& J = jobs[j];
+    if (!J.solver) return fail(GMR_ERR_ARG, "job %d: null solver", j);
+    if (J.S < 0 || J.T < 0) return fail(GMR_ERR_ARG, "job %d: negative S/T", j);
+    if (J.S > 0 && J.T > 0 && (!J.q0 || !J.human || !J.q_out || !J.nsolve || !J.status)) return fail(GMR_ERR_ARG, "job %d: null device buffer", j);
+  }
+  if (!group_is_windowable(jobs, njobs)) return fail(GMR_ERR_ARG, "this batch does not take the throughput shape as a whole: launch it unwindowed");
+  gmr_wide_job_desc wd[8];
+  int nw = 0;
+  void* pool = nullptr;
+  for (int j = 0; j < njobs; j++) {
+    const gmr_job_t& J = jobs[j];
+    if (J.S == 0 || J.T == 0) continue;
+    gmr_solver* s = J.solver;
+    if (nw == 0) pool = s->wide_pool;
+    wd[nw++] = gmr_wide_job_desc{s->d_wide, &s->wide, &s->params, J.S, J.T, J.q0, J.human, J.len, J.q_out, J.nsolve, J.status,
+                                 J.tgt_out, J.err_out};
+  }
+  if (nw == 0) return GMR_OK;
+  hipError_t e = gmr_launch_ik_wide_window(wd, nw, flags, (hipStream_t)stream, nullptr, pool, t_begin, t_end);
+  if (e != hipSuccess) return fail(GMR_ERR_HIP, "window launch: %s", hipGetErrorString(e));
+  return GMR_OK;
+}
+
+// Host buffers of a LONG, NARROW batch (a few thousand streams of hundreds of frames: BASELINE.json configs[3], a dataset
+// batch), overlapped in TIME: the batch is launched as W consecutive windows of frames; the H2D copies of window w + 1
+// (strided: a window of a stream's frames is one piece of its row) run under the kernel of window w, the D2H copies of
+// window w - 1 likewise.  (Cutting such a batch by streams loses: launches narrower than the resident width are bound by
+// their longest stream.)  Three HIP streams, one device workspace holding the whole batch; results are bit-identical to
+// one launch -- the per-stream state travels from window to window in device memory.
+static int retarget_group_windows(const gmr_job_t* jobs, int njobs, int flags, gmr_solver* owner, int W) {
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  struct Off { size_t q0, h, len, qo, ns, st, tg, er; };
+  std::vector<Off> off((size_t)njobs);
+  size_t need = 0;
+  int maxT = 0;
+  for (int j = 0; j < njobs; j++) {
+    const gmr_job_t& J = jobs[j];
+    if (J.S == 0 || J.T == 0) continue;
+    const size_t nq = J.solver->model.nq, nh = J.solver->ts.nhuman, S = (size_t)J.S, T = (size_t)J.T;
+    Off& o = off[j];
+    o.q0 = need; need += up(S * nq * 8);
+    o.h = need; need += up(S * T * nh * 56);
+    o.len = need; need += up(S * 4);
+    o.qo = need; need += up(S * T * nq * 8);
+    o.ns = need; need += up(S * T * 8);
+    o.st = need; need += up(S * 4);
+    o.tg = need; need += J.tgt_out ? up(S * T * nh * 56) : 0;
+    o.er = need; need += J.err_out ? up(S * T * 16) : 0;
+    maxT = std::max(maxT, J.T);
+  }
+  for (int i = 0; i < 3; i++)
+    if (!owner->pipe_stream[i]) HIP_TRY(hipStreamCreateWithFlags(&owner->pipe_stream[i], hipStreamNonBlocking));
+  hipStream_t s_in = owner->pipe_stream[0], s_k = owner->pipe_stream[1], s_out = owner->pipe_stream[2];
+  if (need > owner->pipe_bytes[0]) {
+    for (int i = 0; i < 3; i++) HIP_TRY(hipStreamSynchronize(owner->pipe_stream[i]));
+    if (owner->pipe_ws[0]) (void)hipFree(owner->pipe_ws[0]);
+    owner->pipe_ws[0] = nullptr; owner->pipe_bytes[0] = 0;
+    HIP_TRY(hipMalloc((void**)&owner->pipe_ws[0], need));
+    owner->pipe_bytes[0] = need;
+  }
+  char* d = owner->pipe_ws[0];
+  W = std::max(2, std::min(W, maxT / 2));
+  int wl = (maxT + W - 1) / W;
+  wl += wl & 1;                                       // whole queue items (2 frames) per window
+  std::vector<gmr_job_t> dj((size_t)njobs);
+  std::vector<hipEvent_t> ev;
+  int rc = GMR_OK;
+  hipError_t e = hipSuccess;
+  auto fin = [&](int code) {                          // drain and release whatever was started
+    for (int i = 0; i < 3; i++) (void)hipStreamSynchronize(owner->pipe_stream[i]);
+    for (hipEvent_t x : ev) (void)hipEventDestroy(x);
+    return code;
+  };
+  auto new_event = [&](hipEvent_t* out) { e = hipEventCreateWithFlags(out, hipEventDisableTiming); if (e == hipSuccess) ev.push_back(*out); return e; };
+  for (int j = 0; j < njobs && rc == GMR_OK; j++) {
+    const gmr_job_t& J = jobs[j];
+    gmr_job_t& D = dj[j];
+    D = J;
+    if (J.S == 0 || J.T == 0) continue;
+    const Off& o = off[j];
+    const size_t nq = J.solver->model.nq, nh = J.solver->ts.nhuman, S = (size_t)J.S, T = (size_t)J.T;
+    if ((e = hipMemcpyAsync(d + o.q0, J.q0, S * nq * 8, hipMemcpyHostToDevice, s_in)) != hipSuccess ||
+        (J.len && (e = hipMemcpyAsync(d + o.len, J.len, S * 4, hipMemcpyHostToDevice, s_in)) != hipSuccess))
+      rc = fail(GMR_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
+    if (rc == GMR_OK && (J.len || J.tgt_out || J.err_out)) {      // rows the kernel does not write come back as zeros
+      const size_t end = J.err_out ? o.er + up(S * T * 16) : (J.tgt_out ? o.tg + up(S * T * nh * 56) : o.st + up(S * 4));
+      if ((e = hipMemsetAsync(d + o.qo, 0, end - o.qo, s_k)) != hipSuccess) rc = fail(GMR_ERR_HIP, "memset: %s", hipGetErrorString(e));
+    }
+    D.q0 = (const double*)(d + o.q0); D.human = (const double*)(d + o.h); D.len = J.len ? (const int32_t*)(d + o.len) : nullptr;
+    D.q_out = (double*)(d + o.qo); D.nsolve = (int32_t*)(d + o.ns); D.status = (int32_t*)(d + o.st);
+    D.tgt_out = J.tgt_out ? (double*)(d + o.tg) : nullptr; D.err_out = J.err_out ? (double*)(d + o.er) : nullptr;
+  }
+  for (int tb = 0; tb < maxT && rc == GMR_OK; tb += wl) {
+    const int te = std::min(tb + wl, maxT);
+    for (int j = 0; j < njobs && rc == GMR_OK; j++) {
+      const gmr_job_t& J = jobs[j];
+      if (J.S == 0 || J.T == 0 || tb >= J.T) continue;
+      const size_t row = (size_t)J.solver->ts.nhuman * 56, pitch = (size_t)J.T * row, width = (size_t)(std::min(te, (int)J.T) - tb) * row;
+      if ((e = hipMemcpy2DAsync(d + off[j].h + (size_t)tb * row, pitch, (const char*)J.human + (size_t)tb * row, pitch, width, (size_t)J.S,
+                                hipMemcpyHostToDevice, s_in)) != hipSuccess)
+        rc = fail(GMR_ERR_HIP, "H2D window copy: %s", hipGetErrorString(e));
+    }
+    hipEvent_t e_in = nullptr, e_k = nullptr;
+    if (rc == GMR_OK && (new_event(&e_in) != hipSuccess || (e = hipEventRecord(e_in, s_in)) != hipSuccess ||
+                         (e = hipStreamWaitEvent(s_k, e_in, 0)) != hipSuccess))
+      rc = fail(GMR_ERR_HIP, "window events: %s", hipGetErrorString(e));
+    if (rc == GMR_OK) rc = gmr_retarget_group_window_dev(dj.data(), njobs, flags, tb, te, s_k);
+    if (rc == GMR_OK && (new_event(&e_k) != hipSuccess || (e = hipEventRecord(e_k, s_k)) != hipSuccess ||
+                         (e = hipStreamWaitEvent(s_out, e_k, 0)) != hipSuccess))
+      rc = fail(GMR_ERR_HIP, "window events: %s", hipGetErrorString(e));
+    for (int j = 0; j < njobs && rc == GMR_OK; j++) {
+      const gmr_job_t& J = jobs[j];
+      if (J.S == 0 || J.T == 0 || tb >= J.T) continue;
+      const Off& o = off[j];
+      const size_t nq = J.solver->model.nq, nh = J.solver->ts.nhuman, T = (size_t)J.T, S = (size_t)J.S, n = (size_t)(std::min(te, (int)J.T) - tb);
+      auto back = [&](void* host, size_t dev_off, size_t row) {
+        return hipMemcpy2DAsync((char*)host + (size_t)tb * row, T * row, d + dev_off + (size_t)tb * row, T * row, n * row, S, hipMemcpyDeviceToHost, s_out);
+      };
+      if ((e = back(J.q_out, o.qo, nq * 8)) != hipSuccess || (e = back(J.nsolve, o.ns, 8)) != hipSuccess ||
+          (J.tgt_out && (e = back(J.tgt_out, o.tg, nh * 56)) != hipSuccess) || (J.err_out && (e = back(J.err_out, o.er, 16)) != hipSuccess))
+        rc = fail(GMR_ERR_HIP, "D2H window copy: %s", hipGetErrorString(e));
+    }
+  }
+  for (int j = 0; j < njobs && rc == GMR_OK; j++) {
+    const gmr_job_t& J = jobs[j];
+    if (J.S == 0 || J.T == 0) continue;
+    if ((e = hipMemcpyAsync(J.status, d + off[j].st, (size_t)J.S * 4, hipMemcpyDeviceToHost, s_out)) != hipSuccess)
+      rc = fail(GMR_ERR_HIP, "D2H copy: %s", hipGetErrorString(e));
+  }
+  for (int i = 0; i < 3 && rc == GMR_OK; i++)
+    if ((e = hipStreamSynchronize(owner->pipe_stream[i])) != hipSuccess) rc = fail(GMR_ERR_HIP, "kernel / copies: %s", hipGetErrorString(e));
+  return fin(rc);
+}
+
 // Host buffers, sliced and overlapped: slice k holds the streams [S_j k / n, S_j (k + 1) / n) of every job; its H2D
 // copies, its (group) launch and its D2H copies go to HIP stream k mod 4 in that order, so the copies of one slice run
 // under the kernels of its neighbours.  Slices are cut only while every slice still has a few thousand streams: a
@@ -413,8 +566,17 @@ int gmr_retarget_group(const gmr_job_t* jobs, int njobs, int flags, int slices) 
   const long long min_slice_streams = 4096;          // twice the resident width of an MI355X (8 wavefronts x 256 CUs)
   int n;
   if (slices > 0) n = (int)std::min<long long>(slices, total);                                   // the caller's choice
+  else if (slices < 0) n = 1;
   else n = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(16, (long long)(in_bytes >> 26)),   // ~64 MB of input per slice
                                                             total / min_slice_streams));
+  // a batch too narrow to be cut by streams but long enough to be cut in time (slices < 0: |slices| windows, the caller's choice)
+  {
+    int maxT = 0;
+    for (int j = 0; j < njobs; j++) if (jobs[j].S > 0) maxT = std::max(maxT, (int)jobs[j].T);
+    const bool want = slices < 0 || (slices == 0 && n == 1 && maxT >= 32 && in_bytes >= ((size_t)64 << 20));
+    if (want && maxT >= 4 && group_is_windowable(jobs, njobs) && !getenv("GMR_NO_WINDOWS"))
+      return retarget_group_windows(jobs, njobs, flags, owner, slices < 0 ? -slices : (int)std::min<size_t>(8, in_bytes >> 26));
+  }
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   int rc = GMR_OK;
   hipError_t e = hipSuccess;

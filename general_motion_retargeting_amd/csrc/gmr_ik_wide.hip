@@ -774,6 +774,9 @@ struct WideQueue {
   unsigned* ring;
   WideStreamState* state;
   int chunk;
+  // group launches only: a WINDOW [t_begin, t_end) of every stream's frames (host pipeline: the copies of window w + 1 run under
+  // the kernel of window w); `windowed` = the per-stream state persists in `state` from launch to launch
+  int t_begin, t_end, windowed;
 };
 
 // job of global stream g (MULTI launches): lane l holds first_l, the job is the last one whose first stream is <= g
@@ -799,8 +802,10 @@ __global__ void wide_queue_init(WideJobTable tab, WideJob* __restrict__ d_jobs, 
     const int T = tab.job[j].T;
     const int32_t* len = tab.job[j].len;
     const int Ts = len ? min(max(len[(int)i - tab.job[j].first], 0), T) : T;
-    n = Ts > 0 ? (unsigned)((Ts + Q.chunk - 1) / Q.chunk) : 1u;       // an empty stream is one (empty) chunk
-    Q.state[i] = WideStreamState{0ull, 0ull, 0, GMR_STATUS_OK};
+    const int Tw = min(Ts, Q.t_end), t0 = Q.windowed ? min(Q.t_begin, Ts) : 0;      // this launch's share of the stream
+    n = Tw > t0 ? (unsigned)((Tw - t0 + Q.chunk - 1) / Q.chunk) : 1u;             // nothing to do is one (empty) chunk
+    if (!Q.windowed || Q.t_begin == 0) Q.state[i] = WideStreamState{0ull, 0ull, 0, GMR_STATUS_OK};
+    // (a later window finds t_next where the previous one stopped: t_begin, or the stream's end)
   }
   if (i < nring) Q.ring[i] = i < (unsigned)tab.total ? i + 1u : 0u;
   for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
@@ -878,7 +883,11 @@ __global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_kernel(
   }
   const int gs = s;
 #define GMR_DIMS_T const WideDims&
+#define GMR_T_END T
+#define GMR_WINDOWED false
 #include "gmr_ik_wide_item.inc"
+#undef GMR_WINDOWED
+#undef GMR_T_END
 #undef GMR_DIMS_T
   }
 #ifdef GMR_IK_PROFILE
@@ -908,7 +917,14 @@ __global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_group_kernel(c
   for (;;) {
   int gs = blockIdx.x, t0 = 0, stat = GMR_STATUS_OK;
   RowState bounds = {0ull, 0ull};
-  if (queued && !queue_pop(Q, nchunk, lane, gs, t0, stat, bounds)) break;
+  if (queued) {
+    if (!queue_pop(Q, nchunk, lane, gs, t0, stat, bounds)) break;
+  } else if (Q.windowed && Q.t_begin > 0) {           // a later window of a direct launch: continue from the parked state
+    const WideStreamState st = Q.state[gs];
+    bounds.lower = uniform64(st.lower); bounds.upper = uniform64(st.upper);
+    t0 = __builtin_amdgcn_readfirstlane(st.t_next);
+    stat = __builtin_amdgcn_readfirstlane(st.stat);
+  }
   typedef const WideJob __attribute__((address_space(4))) CJob;
   const int j = __builtin_amdgcn_readfirstlane(job_of(jobs, njobs, gs, lane));
   CJob* cj = reinterpret_cast<CJob*>(reinterpret_cast<uintptr_t>(jobs + j));
@@ -928,7 +944,11 @@ __global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_group_kernel(c
   const double* prm = img_at<double>(img, IM.prm);
   const size_t fstride = (size_t)nhum * 7;
 #define GMR_DIMS_T const WideDims __attribute__((address_space(4)))&
+#define GMR_T_END Q.t_end
+#define GMR_WINDOWED (Q.windowed != 0)
 #include "gmr_ik_wide_item.inc"
+#undef GMR_WINDOWED
+#undef GMR_T_END
 #undef GMR_DIMS_T
   }
 }
@@ -992,8 +1012,19 @@ struct gmr_wide_job_desc {
 // Launch njobs >= 1 jobs as ONE scheduling domain on `stream`: a single job runs the plain instance (its fields are
 // kernel arguments), several jobs the group instance (job table in the workspace).  Queued dispatch engages when the
 // streams of ALL jobs together outnumber the resident wavefronts.
+// t_begin / t_end: with t_end > 0 the launch covers the frames [t_begin, t_end) of every stream only and runs the group
+// instance; the per-stream state (QP bound sets, next frame, status) stays in the pool's workspace of `stream` for the next
+// window, which must follow on the same stream with t_begin = this t_end (the first window has t_begin = 0).
+extern "C" hipError_t gmr_launch_ik_wide_window(const gmr_wide_job_desc* jd, int njobs, int flags, hipStream_t stream,
+                                                unsigned long long* d_prof, void* pool, int t_begin, int t_end);
+
 extern "C" hipError_t gmr_launch_ik_wide_group(const gmr_wide_job_desc* jd, int njobs, int flags, hipStream_t stream,
                                                unsigned long long* d_prof, void* pool) {
+  return gmr_launch_ik_wide_window(jd, njobs, flags, stream, d_prof, pool, 0, 0);
+}
+
+extern "C" hipError_t gmr_launch_ik_wide_window(const gmr_wide_job_desc* jd, int njobs, int flags, hipStream_t stream,
+                                                unsigned long long* d_prof, void* pool, int t_begin, int t_end) {
   using namespace gmr::wide;
   if (njobs < 1 || njobs > WD_MAX_JOBS) return hipErrorInvalidValue;
   WidePool* p = static_cast<WidePool*>(pool);
@@ -1016,40 +1047,63 @@ extern "C" hipError_t gmr_launch_ik_wide_group(const gmr_wide_job_desc* jd, int 
   if (n == 0) return hipSuccess;
   if (total > 0x7fffffffll) return hipErrorInvalidValue;
   tab.njobs = n; tab.total = (int)total;
-  const bool multi = n > 1;
+  const bool windowed = t_end > 0;
+  if (windowed && (t_begin < 0 || t_begin >= t_end)) return hipErrorInvalidValue;
+  const bool multi = n > 1 || windowed;              // (windows are a feature of the group instance)
+  const int span = windowed ? std::min(maxT, t_end) - t_begin : maxT;      // frames per stream in this launch, at most
   // the ring has one entry per chunk: very long jobs get longer chunks rather than a ring beyond 64 MB (more than 2^24
   // streams cannot be helped by longer chunks: the loop ends at chunk >= T and the launch below is a direct one)
-  auto ring_entries = [&](int c) { long long r = 0; for (int j = 0; j < n; j++) r += (long long)tab.job[j].S * ((tab.job[j].T + c - 1) / c); return r; };
-  while (chunk > 0 && chunk < maxT && ring_entries(chunk) > (1ll << 24)) chunk *= 2;
+  auto ring_entries = [&](int c) {
+    long long r = 0;
+    for (int j = 0; j < n; j++) {
+      const int len = windowed ? std::max(0, std::min(tab.job[j].T, t_end) - t_begin) : tab.job[j].T;
+      r += (long long)tab.job[j].S * std::max(1, (len + c - 1) / c);
+    }
+    return r;
+  };
+  while (chunk > 0 && chunk < span && ring_entries(chunk) > (1ll << 24)) chunk *= 2;
   // queued mode pays only when streams outnumber the resident wavefronts and have more than one chunk
-  const bool queued = p && !d_prof && chunk > 0 && p->slots > 0 && maxT > chunk && total > (long long)p->slots * p->min_streams_per_slot;
+  const bool queued = p && !d_prof && chunk > 0 && p->slots > 0 && span > chunk && total > (long long)p->slots * p->min_streams_per_slot;
   if (queued) nring = ring_entries(chunk);
-  WideQueue Q{nullptr, nullptr, nullptr, 0};
+  WideQueue Q{nullptr, nullptr, nullptr, 0, 0, 0, 0};
+  Q.t_begin = windowed ? t_begin : 0;
+  Q.t_end = windowed ? t_end : 0x7fffffff;
+  Q.windowed = windowed ? 1 : 0;
   WideJob* d_jobs = nullptr;
   int grid = (int)total;
   if (queued || multi) {
     if (!p) return hipErrorInvalidValue;
-    // workspace: [hdr 256 B | job table | ring | per-stream state]
-    const size_t o_jobs = 256, o_ring = 4096, o_state = o_ring + ((size_t)nring * 4 + 255) / 256 * 256;
-    static_assert(256 + sizeof(WideJob) * WD_MAX_JOBS <= 4096, "job table must fit in front of the ring");
-    const size_t bytes = o_state + (queued ? (size_t)total * sizeof(WideStreamState) : 0);
+    // workspace: [hdr 256 B | job table | per-stream state | ring]  (the state sits in front of the ring: its place must not
+    // depend on a window's ring size)
+    const size_t o_jobs = 256, o_state = 4096, o_ring = o_state + ((size_t)total * sizeof(WideStreamState) + 255) / 256 * 256;
+    static_assert(256 + sizeof(WideJob) * WD_MAX_JOBS <= 4096, "job table must fit in front of the state");
+    const size_t bytes = o_ring + (size_t)nring * 4 + 256;
     char* base = nullptr;
     {
       std::lock_guard<std::mutex> g(p->mu);
       QueueWs& w = p->ws[stream];
       if (w.bytes < bytes) {
         hipError_t e = hipSuccess;
-        if (w.base) { if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e; (void)hipFree(w.base); w.base = nullptr; w.bytes = 0; }
-        if ((e = hipMalloc((void**)&w.base, bytes)) != hipSuccess) return e;
+        char* grown = nullptr;
+        if ((e = hipMalloc((void**)&grown, bytes)) != hipSuccess) return e;
+        if (w.base) {
+          // a later window that needs a longer ring than the ones before it: the streams' state moves to the new workspace
+          if (windowed && t_begin > 0 && w.bytes > o_state)
+            e = hipMemcpyAsync(grown + o_state, w.base + o_state, std::min(o_ring, w.bytes) - o_state, hipMemcpyDeviceToDevice, stream);
+          if (e == hipSuccess) e = hipStreamSynchronize(stream);
+          if (e != hipSuccess) { (void)hipFree(grown); return e; }
+          (void)hipFree(w.base);
+        }
+        w.base = grown;
         w.bytes = bytes;
       }
       base = w.base;
     }
     if (multi) d_jobs = reinterpret_cast<WideJob*>(base + o_jobs);
+    Q.state = reinterpret_cast<WideStreamState*>(base + o_state);
     if (queued) {
       Q.hdr = reinterpret_cast<unsigned*>(base);
       Q.ring = reinterpret_cast<unsigned*>(base + o_ring);
-      Q.state = reinterpret_cast<WideStreamState*>(base + o_state);
       Q.chunk = chunk;
       hipError_t e = hipMemsetAsync(base, 0, 256, stream);
       if (e != hipSuccess) return e;

@@ -139,9 +139,17 @@ typedef struct gmr_job {
 } gmr_job_t;
 /* device pointers, asynchronous on `stream` */
 int gmr_retarget_group_dev(const gmr_job_t* jobs, int njobs, int flags, void* stream);
+/* device pointers, ONE WINDOW of every stream's frames, [t_begin, t_end): the windows of a batch are launched in order on one
+ * stream starting at t_begin = 0; q continues from the previous window's last q_out row, the QP's bound sets and the status
+ * travel in device memory.  Bit-identical to one launch.  Only for batches that take the throughput shape as a whole (every
+ * robot decomposes, more than 300 streams in total, at most 8 jobs); GMR_ERR_ARG otherwise. */
+int gmr_retarget_group_window_dev(const gmr_job_t* jobs, int njobs, int flags, int t_begin, int t_end, void* stream);
 /* HOST pointers: the streams are cut into `slices` slices (0 = automatic: about 64 MB of input each, never fewer than
  * 4 096 streams per slice, at most 16; > 0: exactly that many, at most one per stream) whose H2D copies, launch and D2H copies go to one of four HIP streams, so that
- * copy(k+1) || kernel(k) || copy-back(k-1); synchronises before returning.  Use pinned host memory (below) for the
+ * copy(k+1) || kernel(k) || copy-back(k-1); synchronises before returning.  A batch too narrow for that (fewer than 8 192
+ * streams) but long (>= 32 frames, >= 64 MB of input) is cut in TIME instead: consecutive windows of frames
+ * (gmr_retarget_group_window_dev), the strided copies of window w + 1 under the kernel of window w; slices < 0 asks for
+ * |slices| windows explicitly.  Use pinned host memory (below) for the
  * copies to be asynchronous.  gmr_retarget_streams takes this path by itself for inputs of 32 MB and more. */
 int gmr_retarget_group(const gmr_job_t* jobs, int njobs, int flags, int slices);
 /* pinned (page-locked) host memory for the host-pointer entry points; gmr_host_register pins a caller's own buffer */

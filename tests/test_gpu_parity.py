@@ -845,6 +845,53 @@ def test_group_launch_device_pointers_and_pinned_pipeline(hip):
 
 
 @pytest.mark.gpu
+def test_group_windows_in_time_are_bit_identical_to_one_launch(hip):
+    """The host pipeline of a long, narrow batch: consecutive windows of frames (gmr_retarget_group_window_dev), the state of
+    every stream (q, the QP's bound sets, status) carried in device memory.  Ragged lengths, empty streams, a failing
+    stream, windows that end beyond some streams; queued and direct launches; device pointers and host buffers
+    (pageable and pinned, explicit and automatic window counts)."""
+    for counts, T, wins in (([500, 430, 390, 410, 380, 450], 11, 3), ([90, 70, 60, 80, 50, 65], 9, 4)):
+        jobs, _ = _six_robot_batch(hip, counts, T, seed=91, fail=(3, 5, 4))
+        ref = hip.retarget_group(jobs, 0, 1)
+        assert ref[3][2][5] == hip.STATUS_QP_FAILED and sum(int((r[2] != 0).sum()) for r in ref) == 1
+        out = hip.retarget_group(jobs, 0, -wins)
+        for a, o in zip(ref, out):
+            assert all(np.array_equal(x, y) for x, y in zip(a, o))
+        pj = [{"solver": j["solver"], "human": hip.pinned_copy(j["human"]), "q0": hip.pinned_copy(j["q0"]), "lens": j["lens"]} for j in jobs]
+        out = hip.retarget_group(pj, 0, -2, outs=hip.group_outputs(pj, pinned=True))
+        for a, o in zip(ref, out):
+            assert all(np.array_equal(x, y) for x, y in zip(a, o))
+        # device pointers, uneven windows on a caller's stream
+        st = hip.Stream()
+        dev, bufs = [], []
+        for j in jobs:
+            sol, (S, _) = j["solver"], j["human"].shape[:2]
+            b = (hip.DeviceBuffer.from_host(j["q0"]), hip.DeviceBuffer.from_host(j["human"]), hip.DeviceBuffer.from_host(j["lens"]),
+                 hip.DeviceBuffer(S * T * sol.nq * 8), hip.DeviceBuffer(S * T * 8), hip.DeviceBuffer(S * 4))
+            for x in b[3:]:
+                x.zero()
+            bufs.append(b)
+            dev.append((sol, S, T, b[0], b[1], b[2], b[3], b[4], b[5]))
+        for w in ((0, 2), (2, 3), (3, 8), (8, T + 5)):
+            hip.retarget_group_dev(dev, 0, st, window=w)
+        st.sync()
+        for (sol, S, _, *_), b, a in zip(dev, bufs, ref):
+            assert np.array_equal(b[3].to_host((S, T, sol.nq), np.float64), a[0])
+            assert np.array_equal(b[4].to_host((S, T, 2), np.int32), a[1]) and np.array_equal(b[5].to_host((S,), np.int32), a[2])
+        for b in bufs:
+            for x in b:
+                x.free()
+    # one job alone is not a group, but windows still run (the group instance with a table of one)
+    su = get_setup("smplx", "unitree_g1")
+    from general_motion_retargeting_amd import synth
+    human, q0 = synth.make_streams(su.model, su.tt, 400, 10, seed=3)
+    sol = hip.Solver(su.mb, su.ts)
+    one = [{"solver": sol, "human": human, "q0": q0}]
+    a, o = hip.retarget_group(one, 0, 1)[0], hip.retarget_group(one, 0, -3)[0]
+    assert all(np.array_equal(x, y) for x, y in zip(a, o)) and not a[2].any()
+
+
+@pytest.mark.gpu
 def test_full_size_config_lafan1_shape_properties(hip, oracle):
     """BASELINE.json configs[2] at full size on one GPU: 77 ragged streams, ~496 k frames (bvh -> G1, the LAFAN1-shaped
     stand-in of bench.py's leg).  Status, iteration counts, joint limits, unit root quaternions, zeros beyond a clip's

@@ -112,7 +112,9 @@ def measure_mixed(S_total=4096, T=256, reps=3):
     pj = [{"solver": j["solver"], "human": _lib.pinned_copy(j["human"]), "q0": _lib.pinned_copy(j["q0"])} for j in jobs]
     for name, jj, pin, slices in (("host_pageable", hj, False, 1), ("host_pinned_1slice", pj, True, 1),
                                   ("host_pinned_2slices", pj, True, 2), ("host_pinned_4slices", pj, True, 4),
-                                  ("host_pinned_auto", pj, True, 0)):
+                                  ("host_pinned_2windows", pj, True, -2), ("host_pinned_4windows", pj, True, -4),
+                                  ("host_pinned_8windows", pj, True, -8), ("host_pinned_16windows", pj, True, -16),
+                                  ("host_pageable_4windows", hj, False, -4), ("host_pinned_auto", pj, True, 0)):
         res = None
         ts = []
         outs = _lib.group_outputs(jj, pinned=pin)
