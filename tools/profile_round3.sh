@@ -39,8 +39,8 @@ python tools/collect_counters.py ik_streams_kernel $O/pmc_head_fetch $O/pmc_head
 python tools/collect_counters.py ik_wide_kernel $O/pmc_wide_fetch $O/pmc_wide_write $O/pmc_wide_sq $O/pmc_wide_sq2 $O/pmc_wide_sq3 $O/pmc_wide_sq4 > $O/counters_wide.json || exit 6
 python tools/collect_counters.py "" $O/pmc_aux_fetch $O/pmc_aux_write $O/pmc_aux_sq > $O/counters_aux.json || exit 6
 echo "[6] phase shares"
-timeout -k 10 300 python tools/phase_profile.py 100 100 > $O/phase_shares.txt 2>/dev/null || exit 7
-timeout -k 10 300 python tools/phase_profile.py 16384 16 > $O/phase_shares_wide.txt 2>/dev/null || exit 7
+timeout -k 10 300 python tools/phase_profile.py 100 100 > $O/phase_shares.txt 2>$O/phase_shares.err || exit 7
+timeout -k 10 300 python tools/phase_profile.py 16384 16 > $O/phase_shares_wide.txt 2>$O/phase_shares_wide.err || exit 7
 fi
 if [[ $PART == *B* ]]; then
 echo "[7] extras, latency, launch-shape crossover"
