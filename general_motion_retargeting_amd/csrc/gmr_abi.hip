@@ -805,6 +805,16 @@ int gmr_fk_create(int nbody, const int32_t* parent, const float* local_t, const 
     r.next_park = 0;
     r.meta = (t.dof_idx[b] >= 0 ? 1u : 0u) | ((uint32_t)(t.load_slot[b] + 1) << 8) | ((uint32_t)(t.save_slot[b] + 1) << 16) |
              ((uint32_t)t.parent[b] << 24);
+    // exact zeros and ones the walk does not multiply by (fk_body): a unit local rotation, a hinge axis +-e_k
+    if (!getenv("GMR_FK_NO_SPECIAL")) {
+      if (r.r[0] == 0.0f && r.r[1] == 0.0f && r.r[2] == 0.0f && r.r[3] == 1.0f) r.meta |= 2u;
+      for (int a = 0; a < 3 && t.dof_idx[b] >= 0; a++)
+        if (fabs(r.axis[a]) == 1.0 && r.axis[(a + 1) % 3] == 0.0 && r.axis[(a + 2) % 3] == 0.0) {
+          r.meta |= (uint32_t)(a + 1) << 2;
+          r.axis[0] = r.axis[a];                // the one component the walk reads for such a hinge
+          break;
+        }
+    }
   }
   // the split walk: per-wavefront body lists with their own records (gmr_fk_tree.h)
   {

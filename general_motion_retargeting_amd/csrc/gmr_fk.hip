@@ -75,13 +75,41 @@ __device__ __forceinline__ void sincosf_small(float x, float* sn, float* cs) {
   *cs = ((q + 1) & 2) ? -cc : cc;
 }
 
+// fminf without the two canonicalising v_max the compiler puts in front of llvm.minnum (one instruction per body
+// instead of three; NaN handling as v_min_f32 in IEEE mode: a quiet NaN operand loses)
+__device__ __forceinline__ float min1(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// a * b for b = (.., b_k, .., b_w) with the two other components exactly zero (K = 0, 1, 2: x, y, z): the terms of
+// qmul_xyzw that survive, in its order -- the dropped ones are products with an exact zero, added to or subtracted from the
+// running sum without changing it (only the sign of a zero RESULT can differ, and non-finite operands: 0 * inf)
+template <int K>
+__device__ __forceinline__ f4 qmul_axis(f4 a, float bk, float bw) {
+  f4 r;
+  if (K == 0) {
+    r.x = a.w * bk + a.x * bw; r.y = a.y * bw + a.z * bk; r.z = a.z * bw - a.y * bk; r.w = a.w * bw - a.x * bk;
+  } else if (K == 1) {
+    r.x = a.x * bw - a.z * bk; r.y = a.w * bk + a.y * bw; r.z = a.x * bk + a.z * bw; r.w = a.w * bw - a.y * bk;
+  } else {
+    r.x = a.x * bw + a.y * bk; r.y = a.y * bw - a.x * bk; r.z = a.w * bk + a.z * bw; r.w = a.w * bw - a.z * bk;
+  }
+  return r;
+}
+
 // One body of the walk: world rotation `rot` = prot * (r_j * joint(ang)) and the world offset of its origin
-// R(prot) t_j (reference kinematics_model.py:213-246).  Everything in `cur` is wave-uniform (SGPRs).
-// (Measured and not kept: skipping the products with the exact zeros / ones of a unit r_j or an axis +-e_k -- bit-equal,
-// 21 % fewer vector instructions, 25 % more scalar ones for the dispatch, no change in time: DESIGN.md section 4.2.)
+// R(prot) t_j (reference kinematics_model.py:213-246).  Everything in `cur` is wave-uniform (SGPRs), so the record's flags
+// select code, not lanes: a local rotation that is exactly (0, 0, 0, 1) (meta bit 1: r_j * x = x) and a hinge axis that is
+// exactly +-e_k (meta bits [3:2] = k + 1: the joint quaternion has two exact zeros) skip the products whose factor is an
+// exact 0 or 1.  Every shipped robot's hinges are axis-aligned and three quarters of the bodies carry no local rotation:
+// 186 -> ~115 vector instructions for such a body, in a walk that is bound by instruction issue.
 __device__ __forceinline__ void fk_body(const FkBodyRec& cur, float ang, f4 prot, float& wx, float& wy, float& wz, f4& rot) {
   const f4 lr = {cur.r[0], cur.r[1], cur.r[2], cur.r[3]};
-  f4 cr = lr;
+  const bool unit_lr = cur.meta & 2u;
+  const unsigned kind = (cur.meta >> 2) & 3u;
+  qrot_xyzw(prot, cur.t[0], cur.t[1], cur.t[2], wx, wy, wz);
   if (cur.meta & 1u) {
     // dof_to_rot: sin/cos of the float32 half angle; products and the normalisation in float64;
     // rounded to float32 on assignment (kinematics_model.py:21-36, torch_utils.py:353-359).
@@ -94,6 +122,19 @@ __device__ __forceinline__ void fk_body(const FkBodyRec& cur, float ang, f4 prot
     sincosf_small(th, &sf, &cf);
 #endif
     double s = (double)sf, c = (double)cf;
+    if (kind) {
+      const double qk = cur.axis[0] * s, qw = c;      // (the record of such a hinge carries its +-1.0 in axis[0])
+      const double e = fma(qk, qk, fma(qw, qw, -1.0));
+      const double rn = fma(e, fma(e, 0.375, -0.5), 1.0);
+      const float jk = (float)(qk * rn), jw = (float)(qw * rn);
+      if (unit_lr) {
+        rot = kind == 1 ? qmul_axis<0>(prot, jk, jw) : (kind == 2 ? qmul_axis<1>(prot, jk, jw) : qmul_axis<2>(prot, jk, jw));
+      } else {
+        const f4 cr = kind == 1 ? qmul_axis<0>(lr, jk, jw) : (kind == 2 ? qmul_axis<1>(lr, jk, jw) : qmul_axis<2>(lr, jk, jw));
+        rot = qmul_xyzw(prot, cr);
+      }
+      return;
+    }
     double qx = cur.axis[0] * s, qy = cur.axis[1] * s, qz = cur.axis[2] * s, qw = c;
     // quat_unit in float64: x / |q|.  |q|^2 = 1 + e with |e| ~ 1e-7 (float32 sin / cos of one angle, a unit axis), so
     // 1 / |q| = 1 - e/2 + 3 e^2 / 8 to 1e-21: the quotient differs from x / sqrt(|q|^2) by < 1 ulp of float64 and
@@ -105,10 +146,10 @@ __device__ __forceinline__ void fk_body(const FkBodyRec& cur, float ang, f4 prot
     const double rn = fma(e, fma(e, 0.375, -0.5), 1.0);
 #endif
     f4 jr = {(float)(qx * rn), (float)(qy * rn), (float)(qz * rn), (float)(qw * rn)};
-    cr = qmul_xyzw(lr, jr);
+    rot = qmul_xyzw(prot, unit_lr ? jr : qmul_xyzw(lr, jr));
+    return;
   }  // no joint: r_j * (0,0,0,1) == r_j exactly
-  qrot_xyzw(prot, cur.t[0], cur.t[1], cur.t[2], wx, wy, wz);
-  rot = qmul_xyzw(prot, cr);
+  rot = unit_lr ? prot : qmul_xyzw(prot, lr);
 }
 
 constexpr int FK_BLOCK = 64;  // one wave per block
@@ -293,7 +334,10 @@ __global__ __launch_bounds__(64 * FK_MAX_WAVES) void fk_split_kernel(const FkTre
   float* outr = outb + 64 * row;
   float* xtra = outr + (body_rot ? 64 * rrow : 0) + tid;      // extra angle columns [k][lane] (FkTree::nextra)
   float* orow = outb + tid * row;
-  float* rrow_p = outr + tid * rrow;
+  // (the lane's staging rows as 32-bit indices into fsm: through the generic pointers the per-body address is a 64-bit
+  //  multiply-add, a quarter-rate instruction)
+  const unsigned orow_i = (unsigned)(tree->nslot_split * 7 * 64) + (unsigned)(tid * row);
+  const unsigned rrow_i = (unsigned)(tree->nslot_split * 7 * 64 + 64 * row) + (unsigned)(tid * rrow);
   const float* drow = dof + fc * ndof;
   const int i0 = tree->wave_start[wave], i1 = tree->wave_start[wave + 1];
   float zmin = INFINITY;
@@ -301,7 +345,9 @@ __global__ __launch_bounds__(64 * FK_MAX_WAVES) void fk_split_kernel(const FkTre
   // one wait -- and parked in LDS (FkTree::wave_park): the x slot of the body's own position in the lane's staging row, a
   // free y / z slot for an ancestor another wavefront stores, or an extra column.  The frame's root pose travels with the
   // same batch.  (The loop this replaces loaded, waited and stored angle by angle behind two dependent scalar loads
-  // each -- the compiler could not batch them -- : a quarter of a block's lifetime was that serial chain.)
+  // each -- the compiler could not batch them -- : a quarter of a block's lifetime was that serial chain.  Measured and
+  // not kept: the block's 64 dof rows as ONE coalesced read by all wavefronts, scattered to the parking places, then a
+  // barrier -- 0.230 against 0.207 ms: the per-lane loads are not what the block waits for, the extra barrier is felt.)
   const float rpx = root_pos[fc * 3], rpy = root_pos[fc * 3 + 1], rpz = root_pos[fc * 3 + 2];
   const f4 rrot = {root_rot[fc * 4], root_rot[fc * 4 + 1], root_rot[fc * 4 + 2], root_rot[fc * 4 + 3]};
   {
@@ -338,8 +384,8 @@ __global__ __launch_bounds__(64 * FK_MAX_WAVES) void fk_split_kernel(const FkTre
     }
     if (r0.meta & 16u) {
       orow[0] = px; orow[1] = py; orow[2] = pz;
-      if (body_rot) *reinterpret_cast<float4*>(rrow_p) = make_float4(rot.x, rot.y, rot.z, rot.w);
-      if (on) zmin = pz;
+      if (body_rot) *reinterpret_cast<float4*>(&fsm[rrow_i]) = make_float4(rot.x, rot.y, rot.z, rot.w);
+      zmin = pz;                                   // (lanes beyond B walk frame 0 again: the minimum over all frames is the same)
     }
   }
   FkBodyRec nxt = tree->wrec[i0 + 1 < i1 ? i0 + 1 : i0];
@@ -381,10 +427,10 @@ __global__ __launch_bounds__(64 * FK_MAX_WAVES) void fk_split_kernel(const FkTre
       sl[0] = px; sl[64] = py; sl[128] = pz; sl[192] = rot.x; sl[256] = rot.y; sl[320] = rot.z; sl[384] = rot.w;
     }
     if (own) {
-      float* o = orow + 3 * j;
-      o[0] = px; o[1] = py; o[2] = pz;
-      if (body_rot) *reinterpret_cast<float4*>(rrow_p + 4 * j) = make_float4(rot.x, rot.y, rot.z, rot.w);   // one 16-B store: 2-way instead of 8-way bank conflicts
-      if (on) zmin = fminf(zmin, pz);
+      const unsigned oi = orow_i + 3u * (unsigned)j;
+      fsm[oi] = px; fsm[oi + 1] = py; fsm[oi + 2] = pz;
+      if (body_rot) *reinterpret_cast<float4*>(&fsm[rrow_i + 4u * (unsigned)j]) = make_float4(rot.x, rot.y, rot.z, rot.w);   // one 16-B store: 2-way instead of 8-way bank conflicts
+      zmin = min1(zmin, pz);
     }
   }
   if (tree->wave_tail_barrier[wave]) __syncthreads();   // (a wavefront whose list ended before the block's mid-walk barrier)

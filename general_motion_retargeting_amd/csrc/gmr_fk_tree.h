@@ -16,10 +16,11 @@ constexpr int FK_MAX_WAVES = 4;
 struct FkBodyRec {
   float t[3];                 // local translation
   uint32_t meta;              // [0] has a hinge, [15:8] load slot + 1 (0: parent = previous body), [23:16] save slot + 1, [31:24] parent
+                              // [1] r is exactly (0, 0, 0, 1), [3:2] = k + 1: the hinge axis is exactly +-e_k (0: any axis)
                               // split walk: [4] this wavefront stores the body, [5] workgroup barrier BEFORE this body (shared
                               // trunk), [7:6] also save the transform in block-wide LDS slot ([7:6] - 1) for other wavefronts
   float r[4];                 // local rotation xyzw, un-normalised
-  double axis[3];             // normalised hinge axis (float64)
+  double axis[3];             // normalised hinge axis (float64); meta[3:2] != 0: axis[0] = the +-1.0 of e_k
   int32_t dof_idx;            // first dof of the joint or -1
   uint32_t next_park;         // split walk: where the NEXT body of the wavefront's list finds its joint angle (read one body
                               // ahead) -- [31] that body has a joint, [30] extra column (index in [29:0]) instead of a float

@@ -763,6 +763,39 @@ def test_fk_split_walk_is_bit_equal_to_one_wavefront_per_block(hip, monkeypatch)
             assert none is None and np.array_equal(bp_only, bp1), (robot, waves)
 
 
+@pytest.mark.gpu
+def test_fk_exact_zero_and_one_shortcuts_give_the_generic_walk(hip, monkeypatch):
+    """The walk skips products with the exact zeros / ones of a unit local rotation and of an axis-aligned hinge (record
+    flags set by gmr_fk_create).  Every loadable robot tree: the same values as the walk without the shortcuts
+    (GMR_FK_NO_SPECIAL=1), bit for bit except the sign of an exact zero."""
+    from general_motion_retargeting_amd import params
+    from general_motion_retargeting_amd.models import load_kinematics_tree
+    rng = np.random.default_rng(11)
+    seen = 0
+    for robot, xml in params.ROBOT_XML_DICT.items():
+        try:
+            tree = load_kinematics_tree(xml)
+        except AssertionError:
+            continue
+        B = 1500
+        monkeypatch.setenv("GMR_FK_NO_SPECIAL", "1")
+        generic = hip.FkHandle(tree)
+        monkeypatch.delenv("GMR_FK_NO_SPECIAL")
+        fast = hip.FkHandle(tree)
+        dof = rng.uniform(-3.0, 3.0, size=(B, fast.ndof)).astype(np.float32)
+        dof[:7] = 0.0                                            # zero angles: sin = 0 exactly
+        rp = rng.normal(size=(B, 3)).astype(np.float32)
+        rq = rng.normal(size=(B, 4)); rq = (rq / np.linalg.norm(rq, axis=1, keepdims=True)).astype(np.float32)
+        rq[:3] = [0, 0, 0, 1]
+        a, b = generic.fk(rp, rq, dof), fast.fk(rp, rq, dof)
+        for x, y in zip(a[:2], b[:2]):
+            assert np.array_equal(x, y), robot
+            diff = x.view(np.uint32) != y.view(np.uint32)
+            assert not (diff & (x != 0)).any(), robot
+        seen += 1
+    assert seen >= 6
+
+
 SIX_ROBOTS = ["unitree_g1", "booster_t1", "stanford_toddy", "fourier_n1", "engineai_pm01", "hightorque_hi"]
 
 
