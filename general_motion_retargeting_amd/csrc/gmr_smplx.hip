@@ -103,9 +103,13 @@ __device__ __forceinline__ q4 sx_slerp_local(q4 q1, q4 q2, double t) {
 #pragma clang fp contract(off)
 
 // out[Nout][nrow][7]: pos xyz, quat wxyz.  ALIGN: target_time[Nout] (np.linspace(0, N-1, Nout)); else Nout == N.
-// COMPACT: the inputs hold only what the kernel reads -- full_pose[N][P.n][3] in the order of the program's steps (the
-// ancestor closure of the selection), joints[N][P.nrow][3] in output-row order -- so that every fetched line is used:
-// of a 660-byte SMPL-X pose row the walk needs 20 of 55 joints (round-2 counters: 6.3 x the algorithmic traffic).
+// COMPACT: the inputs hold only what the kernel reads, FRAME-MINOR -- full_pose[P.n][3][N] in the order of the program's
+// steps (the ancestor closure of the selection), joints[P.nrow][3][N] in output-row order.  A load instruction of the walk
+// (one component of one joint, 64 consecutive output frames) then reads one short contiguous run of source frames, and
+// the two frames of an interpolation pair sit next to each other in it: every fetched line is consumed by the loads that
+// brought it in.  (Frame-major rows -- a lane's 240 B of poses touched joint by joint over the 200 us its libm chains
+// take, 14 000 lanes per XCD -- kept 14 MB of lines open against 4 MB of L2 and fetched them two to three times:
+// 6.3 x the algorithmic traffic in round 2, unchanged by compact frame-major rows in round 3.)
 template <bool ALIGN, bool COMPACT>
 __global__ __launch_bounds__(SX_BLOCK) void smplx_align_kernel(SmplxProg P, int N, int jstride,
                                                                const float* __restrict__ full_pose,
@@ -128,21 +132,24 @@ __global__ __launch_bounds__(SX_BLOCK) void smplx_align_kernel(SmplxProg P, int 
     ss = min(max(ss, 1), N - 1);
     lo = ss - 1; hi = ss;
   }
-  const int prow = COMPACT ? P.n : P.J, jrow = COMPACT ? P.nrow : jstride;
-  const float* p1 = full_pose + (size_t)idx1 * prow * 3;
-  const float* p2 = full_pose + (size_t)idx2 * prow * 3;
-  const float* jl = joints + (size_t)lo * jrow * 3;
-  const float* jh = joints + (size_t)hi * jrow * 3;
+  // element (joint j, component c) of source frame f: frame-major rows, or frame-minor planes (COMPACT)
+  const size_t pstep = COMPACT ? (size_t)N : 1, pj3 = COMPACT ? 3 * (size_t)N : 3;
+  const float* p1 = full_pose + (COMPACT ? (size_t)idx1 : (size_t)idx1 * P.J * 3);
+  const float* p2 = full_pose + (COMPACT ? (size_t)idx2 : (size_t)idx2 * P.J * 3);
+  const float* jl = joints + (COMPACT ? (size_t)lo : (size_t)lo * jstride * 3);
+  const float* jh = joints + (COMPACT ? (size_t)hi : (size_t)hi * jstride * 3);
   double* orow = out + (size_t)o * P.nrow * 7;
   for (int k = 0; k < P.n; k++) {
     const int j = COMPACT ? k : P.joint[k], d = P.depth[k];
     q4 ql;
+    const float* a1 = p1 + (size_t)j * pj3;
     if (ALIGN) {
-      q4 qa = sx_from_rotvec((double)p1[3 * j], (double)p1[3 * j + 1], (double)p1[3 * j + 2]);
-      q4 qb = sx_from_rotvec((double)p2[3 * j], (double)p2[3 * j + 1], (double)p2[3 * j + 2]);
+      const float* a2 = p2 + (size_t)j * pj3;
+      q4 qa = sx_from_rotvec((double)a1[0], (double)a1[pstep], (double)a1[2 * pstep]);
+      q4 qb = sx_from_rotvec((double)a2[0], (double)a2[pstep], (double)a2[2 * pstep]);
       ql = sx_slerp_local(qa, qb, alpha);
     } else {
-      ql = sx_from_rotvec((double)p1[3 * j], (double)p1[3 * j + 1], (double)p1[3 * j + 2]);
+      ql = sx_from_rotvec((double)a1[0], (double)a1[pstep], (double)a1[2 * pstep]);
     }
     q4 qg = ql;
     if (d > 0) {
@@ -160,12 +167,12 @@ __global__ __launch_bounds__(SX_BLOCK) void smplx_align_kernel(SmplxProg P, int 
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         if (ALIGN) {
-          const float ylo = jl[3 * jj + c], yhi = jh[3 * jj + c];
+          const float ylo = jl[(size_t)jj * pj3 + c * pstep], yhi = jh[(size_t)jj * pj3 + c * pstep];
           const float df = yhi - ylo;                                  // float32 difference (interp1d on a float32 y)
           const double slope = (double)df / (double)(hi - lo);
           w[c] = slope * (t - (double)lo) + (double)ylo;
         } else {
-          w[c] = (double)jl[3 * jj + c];
+          w[c] = (double)jl[(size_t)jj * pj3 + c * pstep];
         }
       }
       w[3] = qg.w; w[4] = qg.x; w[5] = qg.y; w[6] = qg.z;
@@ -427,13 +434,17 @@ int gmr_smplx_align(gmr_smplx_t* h, int N, int jstride, const float* full_pose, 
   std::vector<float> pc((size_t)N * np * 3), jc((size_t)N * nr * 3);
   int rowj[SX_MAX_JOINTS];
   for (int k = 0; k < P.n; k++) if (P.row[k] >= 0) rowj[P.row[k]] = P.joint[k];
-  for (int n = 0; n < N; n++) {
+  for (int n = 0; n < N; n++) {                       // frame-minor planes [joint][component][frame]
     const float* ps = full_pose + (size_t)n * h->J * 3;
     const float* js = joints + (size_t)n * jstride * 3;
-    float* pd = pc.data() + (size_t)n * np * 3;
-    float* jd = jc.data() + (size_t)n * nr * 3;
-    for (size_t k = 0; k < np; k++) { const int j = P.joint[k]; pd[3 * k] = ps[3 * j]; pd[3 * k + 1] = ps[3 * j + 1]; pd[3 * k + 2] = ps[3 * j + 2]; }
-    for (size_t r = 0; r < nr; r++) { const int j = rowj[r]; jd[3 * r] = js[3 * j]; jd[3 * r + 1] = js[3 * j + 1]; jd[3 * r + 2] = js[3 * j + 2]; }
+    for (size_t k = 0; k < np; k++) {
+      const int j = P.joint[k];
+      for (int c = 0; c < 3; c++) pc[(3 * k + c) * (size_t)N + n] = ps[3 * j + c];
+    }
+    for (size_t r = 0; r < nr; r++) {
+      const int j = rowj[r];
+      for (int c = 0; c < 3; c++) jc[(3 * r + c) * (size_t)N + n] = js[3 * j + c];
+    }
   }
   const size_t nb_pose = pc.size() * sizeof(float), nb_j = jc.size() * sizeof(float);
   const size_t nb_t = (size_t)Nout * sizeof(double), nb_out = (size_t)Nout * h->sel.nrow * 7 * sizeof(double);

@@ -212,10 +212,11 @@ int gmr_smplx_align_dev(gmr_smplx_t* h, int N, int jstride, const float* d_full_
                         int Nout, const double* d_target_time, double* d_out, void* stream);
 int gmr_smplx_align(gmr_smplx_t* h, int N, int jstride, const float* full_pose, const float* joints, int Nout,
                     const double* target_time, double* out);
-/* The same on COMPACT inputs -- only what the alignment reads: pose_c f32[N][npose][3] = the axis-angle poses of the
- * selection's ancestor closure in walk order, joints_c f32[N][nrow][3] = the joint of every output row; the two joint lists
- * come from gmr_smplx_compact_layout (either output may be NULL).  The host entry point gmr_smplx_align gathers these
- * itself, so only 34 of the 110 joint triples of a G1 frame cross the bus and every fetched line is used. */
+/* The same on COMPACT inputs -- only what the alignment reads, FRAME-MINOR: pose_c f32[npose][3][N] = the axis-angle poses
+ * of the selection's ancestor closure in walk order, joints_c f32[nrow][3][N] = the joint of every output row (numpy:
+ * full_pose[:, pose_joints].transpose(1, 2, 0)); the two joint lists come from gmr_smplx_compact_layout (either output may
+ * be NULL).  The host entry point gmr_smplx_align gathers these itself, so only 34 of the 110 joint triples of a G1 frame
+ * cross the bus, and a wavefront's load of one component reads one contiguous run of source frames. */
 int gmr_smplx_compact_layout(const gmr_smplx_t* h, int32_t* pose_joints, int* npose, int32_t* row_joints, int* nrow);
 int gmr_smplx_align_compact_dev(gmr_smplx_t* h, int N, const float* d_pose_c, const float* d_joints_c, int Nout,
                                 const double* d_target_time, double* d_out, void* stream);

@@ -72,8 +72,8 @@ out["smplx_align_packed_rows"] = {"out_frames": len(tt), "ms": ms, "algorithmic_
                                   "frac_of_8TBps": byt / ms / 1e6 / 8000.0}
 # the same alignment on COMPACT inputs (what the host entry point uploads): only the closure's poses, only the rows' joints
 pj, rj = hs.compact_layout()
-d_pc = _lib.DeviceBuffer.from_host(np.ascontiguousarray(pose[:, pj]))
-d_jc = _lib.DeviceBuffer.from_host(np.ascontiguousarray(jts[:, rj]))
+d_pc = _lib.DeviceBuffer.from_host(np.ascontiguousarray(pose[:, pj].transpose(1, 2, 0)))
+d_jc = _lib.DeviceBuffer.from_host(np.ascontiguousarray(jts[:, rj].transpose(1, 2, 0)))
 d_o2 = _lib.DeviceBuffer(len(tt) * hs.rows * 56)
 ms = timed(lambda: hs.align_compact_dev(N, d_pc, d_jc, len(tt), d_tt, d_o2))
 same = bool(np.array_equal(d_o.to_host((len(tt), hs.rows, 7), np.float64), d_o2.to_host((len(tt), hs.rows, 7), np.float64)))
