@@ -470,7 +470,7 @@ static int retarget_group_windows(const gmr_job_t* jobs, int njobs, int flags, g
   char* d = owner->pipe_ws[0];
   W = std::max(2, std::min(W, maxT / 2));
   int wl = (maxT + W - 1) / W;
-  wl += wl & 1;                                       // whole queue items (2 frames) per window
+  wl = (wl + 3) / 4 * 4;                              // whole queue items (4 frames) per window
   std::vector<gmr_job_t> dj((size_t)njobs);
   std::vector<hipEvent_t> ev;
   int rc = GMR_OK;

@@ -26,8 +26,11 @@
 #include "gmr_ik_prof.h"
 #include "gmr_ik_wide_layout.h"
 
+#ifndef GMR_WIDE_NO_SCHUR_MFMA
+#define GMR_WIDE_SCHUR_MFMA 1
+#endif
 #ifndef GMR_WIDE_MIN_WAVES
-#define GMR_WIDE_MIN_WAVES 2
+#define GMR_WIDE_MIN_WAVES 3
 #endif
 
 namespace gmr {
@@ -465,10 +468,13 @@ __device__ __forceinline__ int solve_rows(DimsRef D, double* sm, const char* __r
       }
       const double yp = row_bcast_d(b, p) * dinv;            // row p keeps its unscaled b (l = 0 there): scaled after the loop
       b = fma(-l, yp, b);
+#ifdef GMR_WIDE_SCHUR_MFMA
 #pragma unroll
-      // (the Schur products -Y_g Y_g^T on the matrix cores -- v_mfma_f64_16x16x4 with A = B^T = Y_g -- were measured twice:
-      //  -3.5 % in round 2, -1.7 % in round 3 at 158 instead of 229 registers)
+      for (int k = (p + 1 < NL ? p + 2 : p + 1); k < NL; k++) r[k] = fma(-l, row_bcast_d(l, k), r[k]);   // limb columns only
+#else
+#pragma unroll
       for (int k = (p + 1 < NL ? p + 2 : p + 1); k < NV; k++) r[k] = fma(-l, row_bcast_d(l, k), r[k]);
+#endif
       dinv = dinv_next;
     }
     if (is_limb) b *= mydinv;                                // y_p = b_p / sqrt(d_p): the value every later row was given
@@ -478,11 +484,47 @@ __device__ __forceinline__ int solve_rows(DimsRef D, double* sm, const char* __r
 #pragma unroll
     for (int m = 0; m < NL; m++) Lscr[lane * TLD + m] = r[m];
     if (is_trunk) rpart[grp * NT + t] = b;
+#ifdef GMR_WIDE_SCHUR_MFMA
+    // The Schur contributions -Y_g Y_g^T (four 9 x 7 by 7 x 9 products) on the matrix cores.  As row-broadcast + FMA column
+    // updates they are 63 instructions AND nine more live registers per lane (the trunk columns of r[]): 229 registers, two
+    // wavefronts per SIMD.  v_mfma_f64_16x16x4_f64 wants A[i][k] in lane i + 16 k and B[k][j] in lane j + 16 k: with
+    // A = Y_g and B = Y_g^T both operands are the SAME register, filled from the transposes just parked in LDS (lane l reads
+    // Y_g[l & 15][4 s + (l >> 4)] for K-step s); D[row = (l >> 4) + 4 reg][col = l & 15] goes straight to the exchange
+    // buffer.  8 LDS reads + 8 MFMAs; the kernel fits three wavefronts per SIMD.
+    {
+      typedef double d4v __attribute__((ext_vector_type(4)));
+      wsync();
+      const int mi = lane_in & 15, mk = lane_in >> 4;
+      d4v acc[4];
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const double* Lg = sm + LD.lscr + g * 16 * TLD + mi * TLD;
+        const double a0 = Lg[mk];                                   // Y_g[mi][mk]
+        const double a1 = (4 + mk < NL) ? Lg[4 + mk] : 0.0;         // Y_g[mi][4 + mk] (column 7 does not exist)
+        d4v c = {0.0, 0.0, 0.0, 0.0};
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, c, 0, 0, 0);
+        acc[g] = c;
+      }
+      // lane (mi, mk) holds D[mk + 4 ri][mi]: rows 4 .. 15 can belong to the trunk block (ri = 0: rows 0 .. 3 never do); one
+      // predicate per ri, the four groups' stores under it
+#pragma unroll
+      for (int ri = 1; ri < 4; ri++) {
+        const int rowi = mk + 4 * ri;
+        if (mi >= NL && rowi >= NL && mi <= rowi) {
+          double* sp = Spart + ((rowi - NL) * (rowi - NL + 1)) / 2 + (mi - NL);
+#pragma unroll
+          for (int g = 0; g < 4; g++) sp[g * WD_TRI] = -acc[g][ri];
+        }
+      }
+    }
+#else
     if (is_trunk) {                                           // row t of the contribution: columns u <= t only are ever read
       double* sp = Spart + grp * WD_TRI + (t * (t + 1)) / 2;
 #pragma unroll
       for (int u = 0; u < NT; u++) if (u <= t) sp[u] = r[NL + u];
     }
+#endif
     unsigned long long* vcur = vset + 4 * (it & 1);
     if (lane == 0 && bad) atomicOr(&vcur[3], 1ull);
     wsync();                                                                                 // B1
@@ -964,12 +1006,19 @@ __global__ __launch_bounds__(64, GMR_WIDE_MIN_WAVES) void ik_wide_group_kernel(c
 
 namespace {
 
+// diagnostic (occupancy experiments): GMR_WIDE_LDS_PAD=<bytes> makes every launch ask for that much more LDS, so that fewer
+// streams are resident per CU -- how throughput scales with resident wavefronts without touching the kernel
+inline int wide_lds_launch_bytes() {
+  static const int pad = [] { const char* e = getenv("GMR_WIDE_LDS_PAD"); return e ? std::max(0, std::min(atoi(e), 40 * 1024)) : 0; }();
+  return gmr::WD_LDS_BYTES + pad;
+}
+
 struct QueueWs { char* base = nullptr; size_t bytes = 0; };
 struct WidePool {
   std::mutex mu;
   std::map<hipStream_t, QueueWs> ws;       // one workspace per HIP stream: launches on one stream are ordered
   int slots = 0;                           // resident wavefronts of the device (the queued grid)
-  int chunk = 2;                           // frames per queue item
+  int chunk = 4;                           // frames per queue item (measured at nine streams per CU: 1: 15.0, 2: 15.7, 4: 15.8, 8: 15.2 M frames/s at 16 384 x 16)
   int min_streams_per_slot = 1;            // queued mode from slots * this + 1 streams (all resident: nothing to balance)
 };
 
@@ -980,8 +1029,10 @@ extern "C" void* gmr_ik_wide_pool_create() {
   int dev = 0, ncu = 0, nblk = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, reinterpret_cast<const void*>(gmr::wide::ik_wide_kernel), 64,
-                                                   gmr::WD_LDS_BYTES) != hipSuccess)
+                                                   wide_lds_launch_bytes()) != hipSuccess)
     ncu = nblk = 0;
+  // (the API assumes 512-byte LDS granules; the device hands out 1 280-byte ones: tools/micro/lds_occupancy.hip)
+  nblk = std::min(nblk, 160 * 1024 / ((wide_lds_launch_bytes() + gmr::WD_LDS_GRANULE - 1) / gmr::WD_LDS_GRANULE * gmr::WD_LDS_GRANULE));
   p->slots = ncu * nblk;
   if (const char* e = getenv("GMR_IK_CHUNK")) p->chunk = atoi(e);      // 0 = always direct
   if (const char* e = getenv("GMR_IK_QUEUE_MIN")) p->min_streams_per_slot = std::max(1, atoi(e));
@@ -1115,10 +1166,10 @@ extern "C" hipError_t gmr_launch_ik_wide_window(const gmr_wide_job_desc* jd, int
     if (e != hipSuccess) return e;
   }
   if (multi) {
-    hipLaunchKernelGGL(ik_wide_group_kernel, dim3(grid), dim3(64), gmr::WD_LDS_BYTES, stream, d_jobs, n, (int)total, flags, Q);
+    hipLaunchKernelGGL(ik_wide_group_kernel, dim3(grid), dim3(64), wide_lds_launch_bytes(), stream, d_jobs, n, (int)total, flags, Q);
   } else {
     const WideJob& J = tab.job[0];
-    hipLaunchKernelGGL(ik_wide_kernel, dim3(grid), dim3(64), gmr::WD_LDS_BYTES, stream, J.img, J.D, J.max_iter, J.human_root,
+    hipLaunchKernelGGL(ik_wide_kernel, dim3(grid), dim3(64), wide_lds_launch_bytes(), stream, J.img, J.D, J.max_iter, J.human_root,
                        J.use0, J.use1, J.S, J.T, J.q0, J.human, J.len, flags, J.q_out, J.nsolve, J.status, J.tgt_out, J.err_out, Q,
                        d_prof);
   }

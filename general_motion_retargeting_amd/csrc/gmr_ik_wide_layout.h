@@ -60,7 +60,6 @@ constexpr WideLds wide_lds() {
   WideLds L{};
   int o = 0;
   L.q = o; o += 7 + WD_NH + 1;
-  L.hsc = o; o += 2 * WD_NH;
   L.xa = o; o += 7 * WD_NB + 1;
   L.xaxis = o; o += 3 * WD_NB;
   L.tgt = o; o += 7 * WD_NHUM + 1;
@@ -78,6 +77,10 @@ constexpr WideLds wide_lds() {
   // region B
   L.Jw = o; o += 6 * (WD_P + 1);                // row WD_P is kept zero: what the padding items of the schedule read
   L.xb = L.Jw;                                // FK runs between solves, when this region is dead
+  // the solver's result and the half-angle sines / cosines live between a solve and the FK after it (integrate reads x and
+  // writes hsc, FK reads hsc; hinge_sincos -> FK at the start of an item), when this region is dead as well
+  L.hsc = L.Jw;
+  L.x = L.Jw + 2 * WD_NH + 4;
   int t = L.Jw;
   L.lscr = t; t += 4 * 16 * WD_LD;
   L.tsh = t; t += WD_NT * WD_TT;
@@ -86,7 +89,7 @@ constexpr WideLds wide_lds() {
   L.xl = t; t += 64;
   if (t > o) o = t;
   if (o & 1) o++;
-  L.c = o; o += 36; L.x = o; o += 36; L.lo = o; o += 36; L.hi = o; o += 36;
+  L.c = o; o += 36; L.lo = o; o += 36; L.hi = o; o += 36;
   L.vset = o; o += 8;
   L.n_double = o;
   return L;
@@ -94,7 +97,10 @@ constexpr WideLds wide_lds() {
 constexpr int WD_LDS_BYTES = wide_lds().n_double * 8;
 static_assert(7 * WD_NB + 1 <= 6 * WD_P, "the second FK buffer must fit the Jw region");
 static_assert(wide_lds().xl + 64 <= wide_lds().Jw + 6 * WD_P, "the solver scratch must fit the Jw region");
-static_assert(WD_LDS_BYTES * 8 <= 160 * 1024, "eight streams per CU");
+// LDS is handed out in granules of 1 280 bytes on gfx950 (measured: tools/micro/lds_occupancy.hip; the occupancy API says 512)
+constexpr int WD_LDS_GRANULE = 1280;
+static_assert((WD_LDS_BYTES + WD_LDS_GRANULE - 1) / WD_LDS_GRANULE * WD_LDS_GRANULE * 9 <= 160 * 1024, "nine streams per CU");
+static_assert(2 * WD_NH + 4 + 36 <= 4 * 16 * WD_LD, "x and hsc must fit the head of the solver scratch");
 static_assert(7 * WD_NHUM + 1 <= 18 * WD_K, "raw frame must fit the M region");
 static_assert(5 * WD_K <= WD_P, "eaux must fit the cpart region");
 
