@@ -102,6 +102,12 @@ def _executed_frac(nsolve, seconds):
             "executed_frac_all_lanes_live": w["executed_fp64_flop_per_solve_all_lanes_live"] * nsolve / seconds / 1e12 / FP64_VALU_PEAK_TFLOPS,
             "mean_active_lane_fraction": w.get("mean_active_lane_fraction_of_valu"), "valu_per_solve": w.get("valu_per_solve"),
             "lds_bank_conflict_share": w.get("lds_bank_conflict_share"),
+            "mfma_f64": {"insts_per_solve": w.get("mfma_f64_insts_per_solve"),
+                         "achieved_tflops": (w.get("mfma_f64_flop_per_solve") or 0.0) * nsolve / seconds / 1e12,
+                         "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                         "frac": (w.get("mfma_f64_flop_per_solve") or 0.0) * nsolve / seconds / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                         "note": "the Schur products of the tree solver (four 9x7 by 7x9 per factorisation) as v_mfma_f64_16x16x4; "
+                                 "MI355X FP64 matrix peak = FP64 vector peak (spec sheet)"},
             "executed_source": "profiles/traffic.json `wide` (rocprofv3 PMC, same kernel sources as HEAD) x the solve count of this run"}
 
 

@@ -124,11 +124,15 @@ if os.path.exists(wide_fp):
         "int32_share_of_valu": g("SQ_INSTS_VALU_INT32") / g("SQ_INSTS_VALU"),
         "lds_bank_conflict_share": g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE") if g("SQ_LDS_IDX_ACTIVE") else None,
         "mean_active_lane_fraction_of_valu": lane_util,
+        "mfma_f64_insts_per_solve": g("SQ_INSTS_VALU_MFMA_F64") / solves,
+        "mfma_f64_flop_per_solve": 2048.0 * g("SQ_INSTS_VALU_MFMA_F64") / solves,      # v_mfma_f64_16x16x4: 16 x 16 x 4 FMA
         "executed_fp64_flop_per_solve_all_lanes_live": flop_all_lanes / solves,
         "executed_fp64_flop_per_solve": flop_all_lanes / solves * (lane_util or 1.0),
         "note": "executed flop = 64 lanes x (2 FMA + MUL + ADD + TRANS) FP64 wave-instructions per launch; multiplied by the mean "
                 "active-lane fraction of VALU instructions (SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU), all VALU types) for the "
-                "second figure.  bench.py turns it into `fp64_valu.executed_frac` with the solve count it measures.",
+                "second figure.  bench.py turns it into `fp64_valu.executed_frac` with the solve count it measures.  The Schur "
+                "products of the tree solver run as v_mfma_f64_16x16x4 (SQ_INSTS_VALU_MFMA_F64, 2 048 flop each, 7 of 16 K-columns "
+                "and 9 x 9 of the 16 x 16 outputs used): counted separately (mfma_f64_*), not in the VALU figures.",
     }
 json.dump(t, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print("published", RND, tag)
