@@ -80,9 +80,9 @@ int gmr_solver_dims(const gmr_solver_t* solver, int* nq, int* nv, int* nhuman);
  * and a trunk of <= 10 (all shipped robots do); other robots always run the 1-wavefront shape.  Results agree
  * to rounding between the shapes; no reference analogue. */
 int gmr_solver_set_waves(gmr_solver_t* solver, int waves_per_stream);
-/* Dispatch of the 1-wavefront shape when streams outnumber the GPU's resident wavefronts (8 per CU):
+/* Dispatch of the 1-wavefront shape when streams outnumber the GPU's resident wavefronts (9 per CU):
  * frames_per_item > 0 = a resident set of wavefronts serves (stream, frames_per_item frames) items from a device-side
- * FIFO, so all streams advance together and the launch does not end on a few late, long streams (default 2);
+ * FIFO, so all streams advance together and the launch does not end on a few late, long streams (default 4);
  * 0 = one workgroup per stream for all of its frames.  Results are bit-identical either way.  The reference's analogue
  * is the chunking of `mp.Pool.map` over files (scripts/smplx_to_robot_dataset.py:241-242). */
 int gmr_solver_set_dispatch(gmr_solver_t* solver, int frames_per_item);

@@ -925,6 +925,30 @@ def test_group_windows_in_time_are_bit_identical_to_one_launch(hip):
 
 
 @pytest.mark.gpu
+def test_large_host_batch_takes_the_windowed_pipeline_by_itself(hip, monkeypatch):
+    """gmr_retarget_streams with >= 64 MB of input in a few thousand streams: the library cuts it into windows of frames on
+    its own (copies of window w + 1 under the kernel of window w).  Ragged lengths; the exported targets and errors travel
+    window by window too; the bits of the same call with the windows switched off (GMR_NO_WINDOWS=1)."""
+    from general_motion_retargeting_amd import synth
+    su = get_setup("smplx", "unitree_g1")
+    S, T = 2400, 36
+    bh, bq = synth.make_streams(su.model, su.tt, 24, T, seed=17)
+    pick = np.arange(S) % 24
+    human, q0 = np.ascontiguousarray(bh[pick]), np.ascontiguousarray(bq[pick])
+    assert human.nbytes >= 64 << 20
+    lens = np.random.default_rng(2).integers(0, T + 1, size=S).astype(np.int32)
+    lens[:3] = [T, 0, 1]
+    sol = hip.Solver(su.mb, su.ts)
+    monkeypatch.setenv("GMR_NO_WINDOWS", "1")
+    ref = sol.retarget_streams(q0, human, lens=lens, want_targets=True, want_errors=True)
+    monkeypatch.delenv("GMR_NO_WINDOWS")
+    out = sol.retarget_streams(q0, human, lens=lens, want_targets=True, want_errors=True)
+    for a, b in zip(ref, out):
+        assert np.array_equal(a, b)
+    assert not ref[2].any() and ref[1][0].min() >= 1 and not ref[0][1].any() and not ref[3][1].any()
+
+
+@pytest.mark.gpu
 def test_full_size_config_lafan1_shape_properties(hip, oracle):
     """BASELINE.json configs[2] at full size on one GPU: 77 ragged streams, ~496 k frames (bvh -> G1, the LAFAN1-shaped
     stand-in of bench.py's leg).  Status, iteration counts, joint limits, unit root quaternions, zeros beyond a clip's
