@@ -20,7 +20,7 @@ SOURCES = ["gmr_ik.hip", "gmr_ik_wide.hip", "gmr_fk.hip", "gmr_smplx.hip", "gmr_
 HEADERS = ["gmr_ik_wide_item.inc", "gmr_device_math.h", "gmr_ik_layout.h", "gmr_ik_wide_layout.h", "gmr_ik_prof.h", "gmr_ik_tree.h",
            "gmr_fk_tree.h", "gmr_internal.h", "../../include/gmr_hip.h", "../../include/gmr_types.h"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
-# The throughput kernel must stay within 256 registers (two wavefronts per SIMD).  Machine-LICM hoists every FP64
+# The throughput kernel must stay within 256 registers (two wavefronts per SIMD; since round 3: 168, three).  Machine-LICM hoists every FP64
 # literal and lane predicate of the (fully inlined) frame loop into registers that live for the whole kernel; they
 # then spill to scratch and are RELOADED inside the loop (99 spilled VGPRs, 336 B of scratch per lane).  Without it
 # and with sinking enabled: 226 VGPRs, no scratch, +13 % frames/s (profiles/r02_*).

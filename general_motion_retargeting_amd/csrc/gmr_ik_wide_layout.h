@@ -9,7 +9,7 @@
 //     the 9 x 9 trunk block: 529 instead of 36 x 37 doubles), written there directly by the assembly schedule;
 //   * the solver's input H is assembled into the space of the residual / -Jl^-1 scratch, the solver's own scratch
 //     lives where the Jacobian columns were: every byte of the assembly is reused by the solve.
-// 18.4 KB per stream instead of 37.5 KB: 8 instead of 4 streams per CU, two wavefronts on every SIMD.
+// 17.3 KB per stream instead of 37.5 KB: 9 instead of 4 streams per CU.
 //
 // Only robots that decompose into <= 4 limbs of <= 7 dofs and a trunk of <= 9 (every shipped robot) and fit the
 // capacities below use this shape; others keep the one-wavefront kernel of gmr_ik.hip with the dense solver.
