@@ -48,15 +48,43 @@ from general_motion_retargeting_amd.models import load_ik_config, load_robot  # 
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (spec sheet)
+def _strip_comments(src: str) -> str:
+    """C / C++ source without comments and with runs of white space collapsed (string and character literals kept)."""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if c in "\"'":
+            j = i + 1
+            while j < n and src[j] != c:
+                j += 2 if src[j] == "\\" else 1
+            out.append(src[i:j + 1])
+            i = j + 1
+        elif src.startswith("//", i):
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif src.startswith("/*", i):
+            j = src.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def kernel_sources_sha256() -> str:
-    """Hash of every kernel / layout source of libgmrhip.so: profiles/traffic.json carries the hash it was measured on."""
+    """Hash of the CODE of every kernel / layout source of libgmrhip.so (comments and white space do not count) and of the
+    compiler flags: profiles/traffic.json carries the hash it was measured on."""
     import hashlib
+    from general_motion_retargeting_amd import build
     h = hashlib.sha256()
     d = os.path.join(ROOT, "general_motion_retargeting_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".h", ".inc")):
             h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+            with open(os.path.join(d, name), "r", errors="replace") as f:
+                h.update(_strip_comments(f.read()).encode())
+    h.update(repr((build.FLAGS, sorted(build.PER_SOURCE_FLAGS.items()))).encode())
     return h.hexdigest()
 
 
