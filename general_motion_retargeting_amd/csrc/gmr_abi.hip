@@ -805,8 +805,10 @@ int gmr_fk_create(int nbody, const int32_t* parent, const float* local_t, const 
     r.next_park = 0;
     r.meta = (t.dof_idx[b] >= 0 ? 1u : 0u) | ((uint32_t)(t.load_slot[b] + 1) << 8) | ((uint32_t)(t.save_slot[b] + 1) << 16) |
              ((uint32_t)t.parent[b] << 24);
-    // exact zeros and ones the walk does not multiply by (fk_body): a unit local rotation, a hinge axis +-e_k
+    // exact zeros and ones the walk does not multiply by (fk_body): a unit local rotation, a hinge axis +-e_k, zero
+    // components of the local translation
     if (!getenv("GMR_FK_NO_SPECIAL")) {
+      for (int a = 0; a < 3; a++) if (r.t[a] == 0.0f) r.next_park |= 1u << (16 + a);
       if (r.r[0] == 0.0f && r.r[1] == 0.0f && r.r[2] == 0.0f && r.r[3] == 1.0f) r.meta |= 2u;
       for (int a = 0; a < 3 && t.dof_idx[b] >= 0; a++)
         if (fabs(r.axis[a]) == 1.0 && r.axis[(a + 1) % 3] == 0.0 && r.axis[(a + 2) % 3] == 0.0) {

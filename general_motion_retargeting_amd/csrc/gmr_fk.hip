@@ -75,6 +75,35 @@ __device__ __forceinline__ void sincosf_small(float x, float* sn, float* cs) {
   *cs = ((q + 1) & 2) ? -cc : cc;
 }
 
+// quat_rotate for a vector with known exact zeros (ZM bit k: component k is exactly 0): the terms of qrot_xyzw that survive,
+// in its order -- a local translation is wave-uniform and most have one or two zero components (G1: 31 of 38 bodies)
+template <bool ZA, bool ZB> __device__ __forceinline__ float diff_z(float a, float b) {
+  if (ZA && ZB) return 0.0f;
+  if (ZA) return -b;
+  if (ZB) return a;
+  return a - b;
+}
+template <bool ZA, bool ZB, bool ZC> __device__ __forceinline__ float sum3_z(float a, float b, float c) {
+  if (ZA && ZB) return c;          // (callers never pass three zeros)
+  if (ZA && ZC) return b;
+  if (ZB && ZC) return a;
+  if (ZA) return b + c;
+  if (ZB) return a + c;
+  if (ZC) return a + b;
+  return a + b + c;
+}
+template <int ZM>
+__device__ __forceinline__ void qrot_sparse(f4 q, float vx, float vy, float vz, float& ox, float& oy, float& oz) {
+  constexpr bool zx = ZM & 1, zy = (ZM >> 1) & 1, zz = (ZM >> 2) & 1;
+  if (zx && zy && zz) { ox = 0.0f; oy = 0.0f; oz = 0.0f; return; }
+  const float s = 2.0f * q.w * q.w - 1.0f;
+  const float cx = diff_z<zz, zy>(q.y * vz, q.z * vy), cy = diff_z<zx, zz>(q.z * vx, q.x * vz), cz = diff_z<zy, zx>(q.x * vy, q.y * vx);
+  const float d = sum3_z<zx, zy, zz>(q.x * vx, q.y * vy, q.z * vz);
+  ox = sum3_z<zx, zy && zz, false>(vx * s, cx * q.w * 2.0f, q.x * d * 2.0f);
+  oy = sum3_z<zy, zz && zx, false>(vy * s, cy * q.w * 2.0f, q.y * d * 2.0f);
+  oz = sum3_z<zz, zx && zy, false>(vz * s, cz * q.w * 2.0f, q.z * d * 2.0f);
+}
+
 // fminf without the two canonicalising v_max the compiler puts in front of llvm.minnum (one instruction per body
 // instead of three; NaN handling as v_min_f32 in IEEE mode: a quiet NaN operand loses)
 __device__ __forceinline__ float min1(float a, float b) {
@@ -109,7 +138,16 @@ __device__ __forceinline__ void fk_body(const FkBodyRec& cur, float ang, f4 prot
   const f4 lr = {cur.r[0], cur.r[1], cur.r[2], cur.r[3]};
   const bool unit_lr = cur.meta & 2u;
   const unsigned kind = (cur.meta >> 2) & 3u;
-  qrot_xyzw(prot, cur.t[0], cur.t[1], cur.t[2], wx, wy, wz);
+  switch ((cur.next_park >> 16) & 7u) {     // which components of t_j are exactly zero (record flags, wave-uniform)
+    case 1: qrot_sparse<1>(prot, cur.t[0], cur.t[1], cur.t[2], wx, wy, wz); break;
+    case 2: qrot_sparse<2>(prot, cur.t[0], cur.t[1], cur.t[2], wx, wy, wz); break;
+    case 3: qrot_sparse<3>(prot, cur.t[0], cur.t[1], cur.t[2], wx, wy, wz); break;
+    case 4: qrot_sparse<4>(prot, cur.t[0], cur.t[1], cur.t[2], wx, wy, wz); break;
+    case 5: qrot_sparse<5>(prot, cur.t[0], cur.t[1], cur.t[2], wx, wy, wz); break;
+    case 6: qrot_sparse<6>(prot, cur.t[0], cur.t[1], cur.t[2], wx, wy, wz); break;
+    case 7: qrot_sparse<7>(prot, cur.t[0], cur.t[1], cur.t[2], wx, wy, wz); break;
+    default: qrot_xyzw(prot, cur.t[0], cur.t[1], cur.t[2], wx, wy, wz); break;
+  }
   if (cur.meta & 1u) {
     // dof_to_rot: sin/cos of the float32 half angle; products and the normalisation in float64;
     // rounded to float32 on assignment (kinematics_model.py:21-36, torch_utils.py:353-359).
@@ -372,7 +410,7 @@ __global__ __launch_bounds__(64 * FK_MAX_WAVES) void fk_split_kernel(const FkTre
   float ang_nxt = 0.0f;
   {
     const FkBodyRec r0 = tree->wrec[i0];           // body 0 opens every list
-    if (r0.next_park >> 31) ang_nxt = *((r0.next_park & 0x40000000u) ? xtra + 64 * (r0.next_park & 0xffffu) : orow + (r0.next_park & 0x3fffffffu));
+    if (r0.next_park >> 31) ang_nxt = *((r0.next_park & 0x40000000u) ? xtra + 64 * (r0.next_park & 0xffffu) : orow + (r0.next_park & 0xffffu));
     const float px = rpx, py = rpy, pz = rpz;
     const f4 rot = rrot;
     cpx = px; cpy = py; cpz = pz; crot = rot;
@@ -403,7 +441,7 @@ __global__ __launch_bounds__(64 * FK_MAX_WAVES) void fk_split_kernel(const FkTre
     const bool own = cur.meta & 16u;
     if (cur.meta & 32u) __syncthreads();           // shared trunk: the transforms this wavefront continues from are parked (fk_build_split)
     const float ang = ang_nxt;                     // parked angle of this body, read while the previous body was walked
-    if (cur.next_park >> 31) ang_nxt = *((cur.next_park & 0x40000000u) ? xtra + 64 * (cur.next_park & 0xffffu) : orow + (cur.next_park & 0x3fffffffu));
+    if (cur.next_park >> 31) ang_nxt = *((cur.next_park & 0x40000000u) ? xtra + 64 * (cur.next_park & 0xffffu) : orow + (cur.next_park & 0xffffu));
     float ppx = cpx, ppy = cpy, ppz = cpz;
     f4 prot = crot;
     if (src == 254) { ppx = spx; ppy = spy; ppz = spz; prot = srot; }

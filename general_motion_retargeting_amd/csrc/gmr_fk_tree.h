@@ -23,8 +23,9 @@ struct FkBodyRec {
   double axis[3];             // normalised hinge axis (float64); meta[3:2] != 0: axis[0] = the +-1.0 of e_k
   int32_t dof_idx;            // first dof of the joint or -1
   uint32_t next_park;         // split walk: where the NEXT body of the wavefront's list finds its joint angle (read one body
-                              // ahead) -- [31] that body has a joint, [30] extra column (index in [29:0]) instead of a float
-                              // offset in the lane's staging row
+                              // ahead) -- [31] that body has a joint, [30] extra column (index in [15:0]) instead of a float
+                              // offset in the lane's staging row ([15:0]); every walk: [18:16] which components of THIS
+                              // body's t are exactly zero
 };
 static_assert(sizeof(FkBodyRec) == 64, "one record = one s_load_dwordx16");
 
@@ -264,7 +265,8 @@ inline const char* fk_build_split(FkTree& t, const int32_t* parent, int maxw) {
     }
     for (int i = i0; i < i1 && park_ok; i++) {
       const int c = i + 1 < i1 ? park_of[i + 1 - i0] : -1;
-      t.wrec[i].next_park = c < 0 ? 0u : (0x80000000u | ((c & 0x8000) ? (0x40000000u | (uint32_t)(c & 0x7fff)) : (uint32_t)c));
+      t.wrec[i].next_park = (t.wrec[i].next_park & 0x70000u) |      // ([18:16]: this body's zero translation components)
+                            (c < 0 ? 0u : (0x80000000u | ((c & 0x8000) ? (0x40000000u | (uint32_t)(c & 0x7fff)) : (uint32_t)c)));
     }
   }
   if (!park_ok) t.nwave = 1;
