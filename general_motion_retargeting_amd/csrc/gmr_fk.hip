@@ -128,6 +128,18 @@ __device__ __forceinline__ f4 qmul_axis(f4 a, float bk, float bw) {
   return r;
 }
 
+// The same for a whole wavefront: when every lane's argument lies in [-0.785, 0.785] -- joint half angles of a humanoid in
+// motion almost always do: |angle| <= 90 degrees -- the reduction (k = 0, r = x exactly) and the quadrant selects fall away:
+// the same two polynomials on the same r, bit-identical, 14 instead of 30 instructions per hinge body.  One ballot decides.
+__device__ __forceinline__ void sincosf_wave(float x, float* sn, float* cs) {
+  if (__builtin_amdgcn_ballot_w64(!(fabsf(x) <= 0.785f)) != 0ull) { sincosf_small(x, sn, cs); return; }
+  const float z = x * x;
+  const float ps = fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f);
+  const float pc = fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f);
+  *sn = fmaf(x * z, ps, x);
+  *cs = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+}
+
 // One body of the walk: world rotation `rot` = prot * (r_j * joint(ang)) and the world offset of its origin
 // R(prot) t_j (reference kinematics_model.py:213-246).  Everything in `cur` is wave-uniform (SGPRs), so the record's flags
 // select code, not lanes: a local rotation that is exactly (0, 0, 0, 1) (meta bit 1: r_j * x = x) and a hinge axis that is
@@ -157,7 +169,7 @@ __device__ __forceinline__ void fk_body(const FkBodyRec& cur, float ang, f4 prot
 #ifdef GMR_FK_LIBM_SINCOS
     sincosf(th, &sf, &cf);
 #else
-    sincosf_small(th, &sf, &cf);
+    sincosf_wave(th, &sf, &cf);
 #endif
     double s = (double)sf, c = (double)cf;
     if (kind) {

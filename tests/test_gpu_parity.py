@@ -796,6 +796,29 @@ def test_fk_exact_zero_and_one_shortcuts_give_the_generic_walk(hip, monkeypatch)
     assert seen >= 6
 
 
+@pytest.mark.gpu
+def test_fk_wavefront_wide_sincos_shortcut_is_bit_identical(hip):
+    """When all 64 frames of a wavefront have a joint's half angle within +-0.785 rad the walk evaluates sin / cos without
+    range reduction.  The same frames walked beside ONE frame with large angles (which sends its wavefront through the
+    reduction) must come out bit for bit the same."""
+    from general_motion_retargeting_amd import params
+    from general_motion_retargeting_amd.models import load_kinematics_tree
+    rng = np.random.default_rng(21)
+    fk = hip.FkHandle(load_kinematics_tree(params.ROBOT_XML_DICT["unitree_g1"]))
+    B = 640
+    dof = rng.uniform(-1.55, 1.55, size=(B, fk.ndof)).astype(np.float32)        # half angles within 0.775
+    rp = rng.normal(size=(B, 3)).astype(np.float32)
+    rq = rng.normal(size=(B, 4)); rq = (rq / np.linalg.norm(rq, axis=1, keepdims=True)).astype(np.float32)
+    a = fk.fk(rp, rq, dof)
+    dof2 = dof.copy()
+    dof2[5::64] = rng.uniform(2.0, 9.0, size=dof2[5::64].shape).astype(np.float32)   # one frame per wavefront
+    b = fk.fk(rp, rq, dof2)
+    keep = np.ones(B, dtype=bool); keep[5::64] = False
+    for x, y in zip(a[:2], b[:2]):
+        assert np.array_equal(x[keep].view(np.uint32), y[keep].view(np.uint32))
+    assert not np.array_equal(a[0][~keep], b[0][~keep])
+
+
 SIX_ROBOTS = ["unitree_g1", "booster_t1", "stanford_toddy", "fourier_n1", "engineai_pm01", "hightorque_hi"]
 
 

@@ -10,7 +10,8 @@ L = _lib.lib()
 km = KinematicsModel(ROBOT_XML_DICT["unitree_g1"]); h = km.hip_handle
 B = 1 << 20
 rng = np.random.default_rng(0)
-dof = rng.uniform(-1, 1, size=(B, 29)).astype(np.float32)
+amp = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+dof = rng.uniform(-amp, amp, size=(B, 29)).astype(np.float32)
 rp = rng.normal(size=(B, 3)).astype(np.float32)
 rq = rng.normal(size=(B, 4)).astype(np.float32); rq /= np.linalg.norm(rq, axis=1, keepdims=True)
 d = [_lib.DeviceBuffer.from_host(a) for a in (rp, rq, dof)]
