@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -40,6 +41,10 @@ struct SmplxProg {
   short depth[SX_MAX_JOINTS];    // its depth (root = 0)
   short row[SX_MAX_JOINTS];      // output row or -1
   short parent[SX_MAX_JOINTS];   // parent JOINT index of step k (joints kernel: rest offsets)
+  // joints kernel: the parent's transform is the previous step's (still in registers: load = -1) or parked in an LDS slot;
+  // only joints with two or more visited children are parked (save >= 0).  SMPL-X: 3 slots instead of 11 stack levels
+  short load[SX_MAX_JOINTS], save[SX_MAX_JOINTS];
+  int nslot;
 };
 
 struct q4 { double x, y, z, w; };   // xyzw like SciPy
@@ -185,16 +190,32 @@ __global__ __launch_bounds__(SX_BLOCK) void smplx_joints_kernel(SmplxProg P, int
                                                                 const float* __restrict__ full_pose,
                                                                 const float* __restrict__ transl,
                                                                 float* __restrict__ joints) {
-  extern __shared__ __align__(16) double stack[];   // [max_depth][12][SX_BLOCK]: R row-major, p
+  // Parked transforms [nslot][12][SX_BLOCK] (R row-major, p), one column per lane.  A depth-indexed stack needs 11 levels for
+  // SMPL-X -- 66 KB, two single-wavefront blocks per CU for a kernel whose time is the latency of its libm chains --; in DFS
+  // order a joint's first child follows it immediately, so only joints with several children are parked: 3 slots, 18 KB.
+  extern __shared__ __align__(16) double stack[];
   const int lane = threadIdx.x;
   const int n = blockIdx.x * SX_BLOCK + lane;
   if (n >= N) return;
   const float* pr = full_pose + (size_t)n * P.J * 3;
   const double tx = transl[(size_t)n * 3], ty = transl[(size_t)n * 3 + 1], tz = transl[(size_t)n * 3 + 2];
   float* jo = joints + (size_t)n * P.J * 3;
+  double Rc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pc[3] = {0, 0, 0};        // the transform of the previous step
+  // (measured and not kept: the innermost slot in 24 registers instead of LDS -- 12 instead of 8 wavefronts per CU, 1.84
+  //  against 1.75 ms: more lanes in flight, more partially written output lines)
+  // the pose of step k + 1 and its rest offset are requested while step k computes (a lane's pose row shares no line with its
+  // neighbours': every read is a trip to L2 that nothing else would hide at two wavefronts per SIMD)
+  float nvx = pr[3 * P.joint[0]], nvy = pr[3 * P.joint[0] + 1], nvz = pr[3 * P.joint[0] + 2];
+  double nrel[3] = {j_rest[3 * P.joint[0]], j_rest[3 * P.joint[0] + 1], j_rest[3 * P.joint[0] + 2]};
   for (int k = 0; k < P.n; k++) {
     const int j = P.joint[k], d = P.depth[k];
-    const double vx = pr[3 * j], vy = pr[3 * j + 1], vz = pr[3 * j + 2];
+    const double vx = nvx, vy = nvy, vz = nvz;
+    const double rel[3] = {nrel[0], nrel[1], nrel[2]};      // step 0: the root's rest position
+    if (k + 1 < P.n) {
+      const int jn = P.joint[k + 1], pn = P.parent[k + 1];
+      nvx = pr[3 * jn]; nvy = pr[3 * jn + 1]; nvz = pr[3 * jn + 2];
+      nrel[0] = j_rest[3 * jn] - j_rest[3 * pn]; nrel[1] = j_rest[3 * jn + 1] - j_rest[3 * pn + 1]; nrel[2] = j_rest[3 * jn + 2] - j_rest[3 * pn + 2];
+    }
     const double ax = vx + 1e-8, ay = vy + 1e-8, az = vz + 1e-8;
     const double ang = sqrt(ax * ax + ay * ay + az * az);
     const double x = vx / ang, y = vy / ang, z = vz / ang, s = sin(ang), c1 = 1.0 - cos(ang);
@@ -213,17 +234,22 @@ __global__ __launch_bounds__(SX_BLOCK) void smplx_joints_kernel(SmplxProg P, int
     if (d == 0) {
 #pragma unroll
       for (int i = 0; i < 9; i++) Rg[i] = Rl[i];
-      pg[0] = j_rest[3 * j]; pg[1] = j_rest[3 * j + 1]; pg[2] = j_rest[3 * j + 2];
+      pg[0] = rel[0]; pg[1] = rel[1]; pg[2] = rel[2];
     } else {
-      const double* sp = stack + (size_t)(d - 1) * 12 * SX_BLOCK + lane;
       double Rp[9], pp[3];
+      const int ld = P.load[k];                       // (uniform)
+      if (ld >= 0) {
+        const double* sp = stack + (size_t)ld * 12 * SX_BLOCK + lane;
 #pragma unroll
-      for (int i = 0; i < 9; i++) Rp[i] = sp[i * SX_BLOCK];
+        for (int i = 0; i < 9; i++) Rp[i] = sp[i * SX_BLOCK];
 #pragma unroll
-      for (int i = 0; i < 3; i++) pp[i] = sp[(9 + i) * SX_BLOCK];
-      const int pj = P.parent[k];
-      const double rel[3] = {j_rest[3 * j] - j_rest[3 * pj], j_rest[3 * j + 1] - j_rest[3 * pj + 1],
-                             j_rest[3 * j + 2] - j_rest[3 * pj + 2]};
+        for (int i = 0; i < 3; i++) pp[i] = sp[(9 + i) * SX_BLOCK];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 9; i++) Rp[i] = Rc[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) pp[i] = pc[i];
+      }
 #pragma unroll
       for (int a = 0; a < 3; a++) {
 #pragma unroll
@@ -236,11 +262,18 @@ __global__ __launch_bounds__(SX_BLOCK) void smplx_joints_kernel(SmplxProg P, int
         pg[a] = pp[a] + Rp[a * 3] * rel[0] + Rp[a * 3 + 1] * rel[1] + Rp[a * 3 + 2] * rel[2];
       }
     }
-    double* so = stack + (size_t)d * 12 * SX_BLOCK + lane;
 #pragma unroll
-    for (int i = 0; i < 9; i++) so[i * SX_BLOCK] = Rg[i];
+    for (int i = 0; i < 9; i++) Rc[i] = Rg[i];
 #pragma unroll
-    for (int i = 0; i < 3; i++) so[(9 + i) * SX_BLOCK] = pg[i];
+    for (int i = 0; i < 3; i++) pc[i] = pg[i];
+    const int sv = P.save[k];                         // (uniform)
+    if (sv >= 0) {
+      double* so = stack + (size_t)sv * 12 * SX_BLOCK + lane;
+#pragma unroll
+      for (int i = 0; i < 9; i++) so[i * SX_BLOCK] = Rg[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) so[(9 + i) * SX_BLOCK] = pg[i];
+    }
     jo[3 * j] = (float)(pg[0] + tx);
     jo[3 * j + 1] = (float)(pg[1] + ty);
     jo[3 * j + 2] = (float)(pg[2] + tz);
@@ -275,6 +308,19 @@ static bool make_prog(int J, const int32_t* parents, const std::vector<char>& ke
   }
   P->n = n;
   P->max_depth = md;
+  // parking slots of the joints kernel: slot of a joint = the number of parked ancestors above it
+  std::vector<int> nkept(J, 0), parked_above(J, 0), slot_of(J, -1);
+  for (int k = 0; k < n; k++) if (k > 0) nkept[P->parent[k]]++;
+  int ns = 0;
+  for (int k = 0; k < n; k++) {
+    const int j = P->joint[k], p = P->parent[k];
+    parked_above[j] = k == 0 ? 0 : parked_above[p] + (nkept[p] >= 2 ? 1 : 0);
+    P->save[k] = -1;
+    if (nkept[j] >= 2) { slot_of[j] = parked_above[j]; P->save[k] = (short)slot_of[j]; ns = std::max(ns, slot_of[j] + 1); }
+    P->load[k] = (short)((k == 0 || P->joint[k - 1] == p) ? -1 : slot_of[p]);
+    if (k > 0 && P->joint[k - 1] != p && slot_of[p] < 0) return false;      // (cannot happen in DFS preorder)
+  }
+  P->nslot = std::max(ns, 1);
   return true;
 }
 
@@ -284,7 +330,23 @@ struct gmr_smplx {
   int J = 0, nsel = 0;
   gmr::SmplxProg all, sel;       // every joint (rows = joint index) / ancestor closure of the selection
   double* d_jrest = nullptr;     // staging of the host entry points
+  char* ws = nullptr;            // their device workspace, grown on demand and kept (a hipMalloc / hipFree pair per clip costs
+  size_t ws_bytes = 0;           //  more than the kernels of a short clip)
+  std::mutex mu;                 // the host entry points of one handle run one at a time (they share d_jrest and ws)
 };
+
+static hipError_t smplx_workspace(gmr_smplx* h, size_t bytes, char** out) {
+  if (bytes > h->ws_bytes) {
+    if (h->ws) (void)hipFree(h->ws);
+    h->ws = nullptr; h->ws_bytes = 0;
+    const size_t want = bytes + bytes / 4;
+    hipError_t e = hipMalloc((void**)&h->ws, want);
+    if (e != hipSuccess) return e;
+    h->ws_bytes = want;
+  }
+  *out = h->ws;
+  return hipSuccess;
+}
 
 extern "C" {
 
@@ -316,7 +378,7 @@ int gmr_smplx_create(int J, const int32_t* parents, int nsel, const int32_t* sel
     h->sel = h->all;
   }
   if (!ok) { delete h; return gmr_fail(GMR_ERR_ARG, "gmr_smplx_create: bad tree or duplicate / out-of-range selection"); }
-  const int lds_align = h->all.max_depth * 4 * SX_BLOCK * 8, lds_joints = h->all.max_depth * 12 * SX_BLOCK * 8;
+  const int lds_align = h->all.max_depth * 4 * SX_BLOCK * 8, lds_joints = h->all.nslot * 12 * SX_BLOCK * 8;
   if (lds_joints > 160 * 1024 - 1024) { delete h; return gmr_fail(GMR_ERR_ARG, "gmr_smplx_create: tree too deep (%d levels)", h->all.max_depth); }
   hipError_t e = hipSuccess;
   if (lds_align > 48 * 1024) {
@@ -336,6 +398,7 @@ int gmr_smplx_create(int J, const int32_t* parents, int nsel, const int32_t* sel
 int gmr_smplx_destroy(gmr_smplx_t* h) {
   if (!h) return GMR_OK;
   (void)hipFree(h->d_jrest);
+  if (h->ws) (void)hipFree(h->ws);
   delete h;
   return GMR_OK;
 }
@@ -346,7 +409,7 @@ int gmr_smplx_joints_dev(gmr_smplx_t* h, int N, const double* d_j_rest, const fl
                          float* d_joints, void* stream) {
   if (!h || N < 0 || !d_j_rest || !d_full_pose || !d_transl || !d_joints) return gmr_fail(GMR_ERR_ARG, "gmr_smplx_joints_dev: bad argument");
   if (N == 0) return GMR_OK;
-  const int lds = h->all.max_depth * 12 * SX_BLOCK * 8;
+  const int lds = h->all.nslot * 12 * SX_BLOCK * 8;
   hipLaunchKernelGGL(gmr::smplx_joints_kernel, dim3((N + SX_BLOCK - 1) / SX_BLOCK), dim3(SX_BLOCK), lds, (hipStream_t)stream,
                      h->all, N, d_j_rest, d_full_pose, d_transl, d_joints);
   hipError_t e = hipGetLastError();
@@ -404,8 +467,9 @@ int gmr_smplx_joints(gmr_smplx_t* h, int N, const double* j_rest, const float* f
   if (!h || N < 0 || !j_rest || !full_pose || !transl || !joints) return gmr_fail(GMR_ERR_ARG, "gmr_smplx_joints: bad argument");
   if (N == 0) return GMR_OK;
   const size_t nb_pose = (size_t)N * h->J * 3 * sizeof(float), nb_tr = (size_t)N * 3 * sizeof(float);
+  std::lock_guard<std::mutex> guard(h->mu);
   char* ws = nullptr;
-  hipError_t e = hipMalloc((void**)&ws, 2 * nb_pose + nb_tr + 64);
+  hipError_t e = smplx_workspace(h, 2 * nb_pose + nb_tr + 64, &ws);
   if (e != hipSuccess) return gmr_fail(GMR_ERR_HIP, "gmr_smplx_joints: %s", hipGetErrorString(e));
   float* d_pose = (float*)ws;
   float* d_j = (float*)(ws + nb_pose);
@@ -418,7 +482,6 @@ int gmr_smplx_joints(gmr_smplx_t* h, int N, const double* j_rest, const float* f
   if (rc == GMR_OK) rc = gmr_smplx_joints_dev(h, N, h->d_jrest, d_pose, d_tr, d_j, nullptr);
   if (rc == GMR_OK && (e = hipMemcpy(joints, d_j, nb_pose, hipMemcpyDeviceToHost)) != hipSuccess)
     rc = gmr_fail(GMR_ERR_HIP, "gmr_smplx_joints: %s", hipGetErrorString(e));
-  (void)hipFree(ws);
   return rc;
 }
 
@@ -449,8 +512,9 @@ int gmr_smplx_align(gmr_smplx_t* h, int N, int jstride, const float* full_pose, 
   const size_t nb_pose = pc.size() * sizeof(float), nb_j = jc.size() * sizeof(float);
   const size_t nb_t = (size_t)Nout * sizeof(double), nb_out = (size_t)Nout * h->sel.nrow * 7 * sizeof(double);
   auto up = [](size_t v) { return (v + 63) / 64 * 64; };
+  std::lock_guard<std::mutex> guard(h->mu);
   char* ws = nullptr;
-  hipError_t e = hipMalloc((void**)&ws, up(nb_pose) + up(nb_j) + up(nb_t) + up(nb_out));
+  hipError_t e = smplx_workspace(h, up(nb_pose) + up(nb_j) + up(nb_t) + up(nb_out), &ws);
   if (e != hipSuccess) return gmr_fail(GMR_ERR_HIP, "gmr_smplx_align: %s", hipGetErrorString(e));
   float* d_pose = (float*)ws;
   float* d_j = (float*)(ws + up(nb_pose));
@@ -464,7 +528,6 @@ int gmr_smplx_align(gmr_smplx_t* h, int N, int jstride, const float* full_pose, 
   if (rc == GMR_OK) rc = gmr_smplx_align_compact_dev(h, N, d_pose, d_j, Nout, target_time ? d_t : nullptr, d_o, nullptr);
   if (rc == GMR_OK && (e = hipMemcpy(out, d_o, nb_out, hipMemcpyDeviceToHost)) != hipSuccess)
     rc = gmr_fail(GMR_ERR_HIP, "gmr_smplx_align: %s", hipGetErrorString(e));
-  (void)hipFree(ws);
   return rc;
 }
 
