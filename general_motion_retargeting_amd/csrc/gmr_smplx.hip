@@ -185,7 +185,32 @@ __global__ __launch_bounds__(SX_BLOCK) void smplx_align_kernel(SmplxProg P, int 
   }
 }
 
-// joints f32[N][J][3] from rest joints f64[J][3], poses f32[N][J][3], translations f32[N][3]
+// dst[C][R] = src[R][C]^T through 64 x 64 LDS tiles: both sides move whole lines.  The joints kernel reads its poses and
+// writes its joints as frame-minor planes [J * 3][N] -- lane = frame, so every load / store instruction is one contiguous run;
+// with frame-major rows a lane's 660-byte row stays open for the 200 us of its walk, and at eight blocks per CU the rows in
+// flight (100 MB) no longer fit the L2: 2.2 GB fetched and 3.0 GB written for 0.69 + 0.69 GB (measured, profiles/r03_v6_*).
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ src, int R, int C, float* __restrict__ dst,
+                                                            int rows_on_x) {
+  __shared__ float tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  // (the frame dimension rides on blockIdx.x: no 65 535 limit)
+  const int c0 = (rows_on_x ? blockIdx.y : blockIdx.x) * 64, r0 = (rows_on_x ? blockIdx.x : blockIdx.y) * 64;
+#pragma unroll 4
+  for (int i = 0; i < 16; i++) {
+    const int r = r0 + ty + 4 * i, c = c0 + tx;
+    if (r < R && c < C) tile[ty + 4 * i][tx] = src[(size_t)r * C + c];
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int i = 0; i < 16; i++) {
+    const int c = c0 + ty + 4 * i, r = r0 + tx;
+    if (r < R && c < C) dst[(size_t)c * R + r] = tile[tx][ty + 4 * i];
+  }
+}
+
+// joints from rest joints f64[J][3], poses, translations f32[N][3].  PLANES: poses and joints are frame-minor planes
+// f32[J * 3][N] (the entry point transposes on either side); else frame-major rows f32[N][J][3]
+template <bool PLANES>
 __global__ __launch_bounds__(SX_BLOCK) void smplx_joints_kernel(SmplxProg P, int N, const double* __restrict__ j_rest,
                                                                 const float* __restrict__ full_pose,
                                                                 const float* __restrict__ transl,
@@ -197,15 +222,19 @@ __global__ __launch_bounds__(SX_BLOCK) void smplx_joints_kernel(SmplxProg P, int
   const int lane = threadIdx.x;
   const int n = blockIdx.x * SX_BLOCK + lane;
   if (n >= N) return;
-  const float* pr = full_pose + (size_t)n * P.J * 3;
+  // element c of joint j of this lane's frame
+  const float* pr = full_pose + (PLANES ? (size_t)n : (size_t)n * P.J * 3);
+  float* jo = joints + (PLANES ? (size_t)n : (size_t)n * P.J * 3);
+  const size_t es = PLANES ? (size_t)N : 1;
   const double tx = transl[(size_t)n * 3], ty = transl[(size_t)n * 3 + 1], tz = transl[(size_t)n * 3 + 2];
-  float* jo = joints + (size_t)n * P.J * 3;
   double Rc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pc[3] = {0, 0, 0};        // the transform of the previous step
-  // (measured and not kept: the innermost slot in 24 registers instead of LDS -- 12 instead of 8 wavefronts per CU, 1.84
-  //  against 1.75 ms: more lanes in flight, more partially written output lines)
+  // the innermost parking slot (SMPL-X: a wrist while its fingers are walked, the head for jaw and eyes) is 24 registers
+  // instead of 6 KB of LDS: 2 slots = 12 KB, twelve blocks per CU
+  const int rslot = P.nslot - 1;
+  double Rs[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, ps[3] = {0, 0, 0};
   // the pose of step k + 1 and its rest offset are requested while step k computes (a lane's pose row shares no line with its
   // neighbours': every read is a trip to L2 that nothing else would hide at two wavefronts per SIMD)
-  float nvx = pr[3 * P.joint[0]], nvy = pr[3 * P.joint[0] + 1], nvz = pr[3 * P.joint[0] + 2];
+  float nvx = pr[(3 * P.joint[0]) * es], nvy = pr[(3 * P.joint[0] + 1) * es], nvz = pr[(3 * P.joint[0] + 2) * es];
   double nrel[3] = {j_rest[3 * P.joint[0]], j_rest[3 * P.joint[0] + 1], j_rest[3 * P.joint[0] + 2]};
   for (int k = 0; k < P.n; k++) {
     const int j = P.joint[k], d = P.depth[k];
@@ -213,7 +242,7 @@ __global__ __launch_bounds__(SX_BLOCK) void smplx_joints_kernel(SmplxProg P, int
     const double rel[3] = {nrel[0], nrel[1], nrel[2]};      // step 0: the root's rest position
     if (k + 1 < P.n) {
       const int jn = P.joint[k + 1], pn = P.parent[k + 1];
-      nvx = pr[3 * jn]; nvy = pr[3 * jn + 1]; nvz = pr[3 * jn + 2];
+      nvx = pr[(3 * jn) * es]; nvy = pr[(3 * jn + 1) * es]; nvz = pr[(3 * jn + 2) * es];
       nrel[0] = j_rest[3 * jn] - j_rest[3 * pn]; nrel[1] = j_rest[3 * jn + 1] - j_rest[3 * pn + 1]; nrel[2] = j_rest[3 * jn + 2] - j_rest[3 * pn + 2];
     }
     const double ax = vx + 1e-8, ay = vy + 1e-8, az = vz + 1e-8;
@@ -238,7 +267,12 @@ __global__ __launch_bounds__(SX_BLOCK) void smplx_joints_kernel(SmplxProg P, int
     } else {
       double Rp[9], pp[3];
       const int ld = P.load[k];                       // (uniform)
-      if (ld >= 0) {
+      if (ld == rslot) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) Rp[i] = Rs[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) pp[i] = ps[i];
+      } else if (ld >= 0) {
         const double* sp = stack + (size_t)ld * 12 * SX_BLOCK + lane;
 #pragma unroll
         for (int i = 0; i < 9; i++) Rp[i] = sp[i * SX_BLOCK];
@@ -267,16 +301,21 @@ __global__ __launch_bounds__(SX_BLOCK) void smplx_joints_kernel(SmplxProg P, int
 #pragma unroll
     for (int i = 0; i < 3; i++) pc[i] = pg[i];
     const int sv = P.save[k];                         // (uniform)
-    if (sv >= 0) {
+    if (sv == rslot) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) Rs[i] = Rg[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) ps[i] = pg[i];
+    } else if (sv >= 0) {
       double* so = stack + (size_t)sv * 12 * SX_BLOCK + lane;
 #pragma unroll
       for (int i = 0; i < 9; i++) so[i * SX_BLOCK] = Rg[i];
 #pragma unroll
       for (int i = 0; i < 3; i++) so[(9 + i) * SX_BLOCK] = pg[i];
     }
-    jo[3 * j] = (float)(pg[0] + tx);
-    jo[3 * j + 1] = (float)(pg[1] + ty);
-    jo[3 * j + 2] = (float)(pg[2] + tz);
+    jo[(3 * j) * es] = (float)(pg[0] + tx);
+    jo[(3 * j + 1) * es] = (float)(pg[1] + ty);
+    jo[(3 * j + 2) * es] = (float)(pg[2] + tz);
   }
 }
 
@@ -333,6 +372,8 @@ struct gmr_smplx {
   char* ws = nullptr;            // their device workspace, grown on demand and kept (a hipMalloc / hipFree pair per clip costs
   size_t ws_bytes = 0;           //  more than the kernels of a short clip)
   std::mutex mu;                 // the host entry points of one handle run one at a time (they share d_jrest and ws)
+  char* planes = nullptr;        // gmr_smplx_joints_dev: the transposed poses and joints of the launch in flight (one stream at
+  size_t planes_bytes = 0;       //  a time per handle)
 };
 
 static hipError_t smplx_workspace(gmr_smplx* h, size_t bytes, char** out) {
@@ -378,7 +419,7 @@ int gmr_smplx_create(int J, const int32_t* parents, int nsel, const int32_t* sel
     h->sel = h->all;
   }
   if (!ok) { delete h; return gmr_fail(GMR_ERR_ARG, "gmr_smplx_create: bad tree or duplicate / out-of-range selection"); }
-  const int lds_align = h->all.max_depth * 4 * SX_BLOCK * 8, lds_joints = h->all.nslot * 12 * SX_BLOCK * 8;
+  const int lds_align = h->all.max_depth * 4 * SX_BLOCK * 8, lds_joints = std::max(h->all.nslot - 1, 1) * 12 * SX_BLOCK * 8;
   if (lds_joints > 160 * 1024 - 1024) { delete h; return gmr_fail(GMR_ERR_ARG, "gmr_smplx_create: tree too deep (%d levels)", h->all.max_depth); }
   hipError_t e = hipSuccess;
   if (lds_align > 48 * 1024) {
@@ -388,7 +429,10 @@ int gmr_smplx_create(int J, const int32_t* parents, int nsel, const int32_t* sel
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gmr::smplx_align_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_align);
   }
   if (e == hipSuccess && lds_joints > 48 * 1024)
-    e = hipFuncSetAttribute((const void*)gmr::smplx_joints_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_joints);
+    {
+    e = hipFuncSetAttribute((const void*)gmr::smplx_joints_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_joints);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gmr::smplx_joints_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_joints);
+  }
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_jrest, (size_t)J * 3 * sizeof(double));
   if (e != hipSuccess) { delete h; return gmr_fail(GMR_ERR_HIP, "gmr_smplx_create: %s", hipGetErrorString(e)); }
   *out = h;
@@ -399,6 +443,7 @@ int gmr_smplx_destroy(gmr_smplx_t* h) {
   if (!h) return GMR_OK;
   (void)hipFree(h->d_jrest);
   if (h->ws) (void)hipFree(h->ws);
+  if (h->planes) (void)hipFree(h->planes);
   delete h;
   return GMR_OK;
 }
@@ -409,9 +454,29 @@ int gmr_smplx_joints_dev(gmr_smplx_t* h, int N, const double* d_j_rest, const fl
                          float* d_joints, void* stream) {
   if (!h || N < 0 || !d_j_rest || !d_full_pose || !d_transl || !d_joints) return gmr_fail(GMR_ERR_ARG, "gmr_smplx_joints_dev: bad argument");
   if (N == 0) return GMR_OK;
-  const int lds = h->all.nslot * 12 * SX_BLOCK * 8;
-  hipLaunchKernelGGL(gmr::smplx_joints_kernel, dim3((N + SX_BLOCK - 1) / SX_BLOCK), dim3(SX_BLOCK), lds, (hipStream_t)stream,
-                     h->all, N, d_j_rest, d_full_pose, d_transl, d_joints);
+  const int lds = std::max(h->all.nslot - 1, 1) * 12 * SX_BLOCK * 8;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((N + SX_BLOCK - 1) / SX_BLOCK), block(SX_BLOCK);
+  static const bool rows = getenv("GMR_SMPLX_ROWS") != nullptr;       // A/B: the walk on frame-major rows
+  if (rows) {
+    hipLaunchKernelGGL(gmr::smplx_joints_kernel<false>, grid, block, lds, st, h->all, N, d_j_rest, d_full_pose, d_transl, d_joints);
+  } else {
+    const int C = h->J * 3;
+    const size_t plane = ((size_t)N * C * sizeof(float) + 255) / 256 * 256;
+    if (2 * plane > h->planes_bytes) {
+      hipError_t e = hipStreamSynchronize(st);                        // (the launch in flight may still use the old block)
+      if (e != hipSuccess) return gmr_fail(GMR_ERR_HIP, "gmr_smplx_joints_dev: %s", hipGetErrorString(e));
+      if (h->planes) (void)hipFree(h->planes);
+      h->planes = nullptr; h->planes_bytes = 0;
+      if ((e = hipMalloc((void**)&h->planes, 2 * plane + plane / 2)) != hipSuccess) return gmr_fail(GMR_ERR_HIP, "gmr_smplx_joints_dev: %s", hipGetErrorString(e));
+      h->planes_bytes = 2 * plane + plane / 2;
+    }
+    float* pose_t = reinterpret_cast<float*>(h->planes);
+    float* joints_t = reinterpret_cast<float*>(h->planes + h->planes_bytes / 2 / 256 * 256);
+    hipLaunchKernelGGL(gmr::transpose_f32_kernel, dim3((N + 63) / 64, (C + 63) / 64), dim3(256), 0, st, d_full_pose, N, C, pose_t, 1);
+    hipLaunchKernelGGL(gmr::smplx_joints_kernel<true>, grid, block, lds, st, h->all, N, d_j_rest, pose_t, d_transl, joints_t);
+    hipLaunchKernelGGL(gmr::transpose_f32_kernel, dim3((N + 63) / 64, (C + 63) / 64), dim3(256), 0, st, joints_t, C, N, d_joints, 0);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return gmr_fail(GMR_ERR_HIP, "smplx_joints_kernel: %s", hipGetErrorString(e));
   return GMR_OK;
