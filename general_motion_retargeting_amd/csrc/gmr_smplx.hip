@@ -192,19 +192,39 @@ __global__ __launch_bounds__(SX_BLOCK) void smplx_align_kernel(SmplxProg P, int 
 __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ src, int R, int C, float* __restrict__ dst,
                                                             int rows_on_x) {
   __shared__ float tile[64][65];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   // (the frame dimension rides on blockIdx.x: no 65 535 limit)
   const int c0 = (rows_on_x ? blockIdx.y : blockIdx.x) * 64, r0 = (rows_on_x ? blockIdx.x : blockIdx.y) * 64;
-#pragma unroll 4
-  for (int i = 0; i < 16; i++) {
-    const int r = r0 + ty + 4 * i, c = c0 + tx;
-    if (r < R && c < C) tile[ty + 4 * i][tx] = src[(size_t)r * C + c];
+  // 16 bytes per lane on both sides (dword-aligned vector accesses: a 660-byte row starts anywhere): lane group g = t >> 4
+  // takes a row of the tile, lane q = t & 15 four consecutive elements of it
+  const int q = (threadIdx.x & 15) * 4, g = threadIdx.x >> 4;
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int r = r0 + g + 16 * i, c = c0 + q;
+    if (r < R) {
+      const float* p = src + (size_t)r * C + c;
+      if (c + 3 < C) {
+        const f4u v = *reinterpret_cast<const f4u*>(p);
+        tile[g + 16 * i][q] = v.x; tile[g + 16 * i][q + 1] = v.y; tile[g + 16 * i][q + 2] = v.z; tile[g + 16 * i][q + 3] = v.w;
+      } else {
+        for (int k = 0; k < 4 && c + k < C; k++) tile[g + 16 * i][q + k] = p[k];
+      }
+    }
   }
   __syncthreads();
-#pragma unroll 4
-  for (int i = 0; i < 16; i++) {
-    const int c = c0 + ty + 4 * i, r = r0 + tx;
-    if (r < R && c < C) dst[(size_t)c * R + r] = tile[tx][ty + 4 * i];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = c0 + g + 16 * i, r = r0 + q;
+    if (c < C) {
+      float* p = dst + (size_t)c * R + r;
+      if (r + 3 < R) {
+        f4u v;
+        v.x = tile[q][g + 16 * i]; v.y = tile[q + 1][g + 16 * i]; v.z = tile[q + 2][g + 16 * i]; v.w = tile[q + 3][g + 16 * i];
+        *reinterpret_cast<f4u*>(p) = v;
+      } else {
+        for (int k = 0; k < 4 && r + k < R; k++) p[k] = tile[q + k][g + 16 * i];
+      }
+    }
   }
 }
 
