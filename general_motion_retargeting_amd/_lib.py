@@ -79,6 +79,7 @@ _SIGS = {
                                       C.c_void_p, C.c_void_p]),
     "gmr_smplx_align": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_void_p]),
+    "gmr_smplx_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "gmr_smplx_compact_layout": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int)]),
     "gmr_smplx_align_compact_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                               C.c_void_p]),
@@ -551,6 +552,21 @@ class SmplxHandle:
         out = np.zeros((nout, self.rows, 7), dtype=np.float64)
         check(lib().gmr_smplx_align(self.handle, N, int(joints.shape[1]), _ptr(full_pose), _ptr(joints), nout, _ptr(tt),
                                     _ptr(out)))
+        return out
+
+    def frames(self, j_rest, full_pose, transl, target_time=None):
+        """Joints-only body model + alignment of the selected rows in one call (``gmr_smplx_frames``): the packed frames
+        ``f64[Nout, rows, 7]`` only; bit-identical to :meth:`joints` followed by :meth:`align`."""
+        full_pose = np.ascontiguousarray(full_pose, dtype=np.float32).reshape(-1, self.J, 3)
+        N = full_pose.shape[0]
+        j_rest = np.ascontiguousarray(j_rest, dtype=np.float64)
+        transl = np.ascontiguousarray(transl, dtype=np.float32).reshape(N, 3)
+        if j_rest.shape != (self.J, 3):
+            raise ValueError(f"j_rest must be [{self.J}, 3]")
+        tt = None if target_time is None else np.ascontiguousarray(target_time, dtype=np.float64)
+        nout = N if tt is None else len(tt)
+        out = np.empty((nout, self.rows, 7), dtype=np.float64)
+        check(lib().gmr_smplx_frames(self.handle, N, _ptr(j_rest), _ptr(full_pose), _ptr(transl), nout, _ptr(tt), _ptr(out)))
         return out
 
     def compact_layout(self):

@@ -137,6 +137,9 @@ __global__ __launch_bounds__(SX_BLOCK) void smplx_align_kernel(SmplxProg P, int 
     ss = min(max(ss, 1), N - 1);
     lo = ss - 1; hi = ss;
   }
+  // COMPACT with jstride < 0: the planes are those of ALL joints, indexed by joint (what the joints kernel reads and writes:
+  // gmr_smplx_frames runs both steps without a gather in between)
+  const bool byjoint = COMPACT && jstride < 0;
   // element (joint j, component c) of source frame f: frame-major rows, or frame-minor planes (COMPACT)
   const size_t pstep = COMPACT ? (size_t)N : 1, pj3 = COMPACT ? 3 * (size_t)N : 3;
   const float* p1 = full_pose + (COMPACT ? (size_t)idx1 : (size_t)idx1 * P.J * 3);
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(SX_BLOCK) void smplx_align_kernel(SmplxProg P, int 
   const float* jh = joints + (COMPACT ? (size_t)hi : (size_t)hi * jstride * 3);
   double* orow = out + (size_t)o * P.nrow * 7;
   for (int k = 0; k < P.n; k++) {
-    const int j = COMPACT ? k : P.joint[k], d = P.depth[k];
+    const int j = (COMPACT && !byjoint) ? k : P.joint[k], d = P.depth[k];
     q4 ql;
     const float* a1 = p1 + (size_t)j * pj3;
     if (ALIGN) {
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(SX_BLOCK) void smplx_align_kernel(SmplxProg P, int 
     const int r = P.row[k];
     if (r >= 0) {
       double* w = orow + r * 7;
-      const int jj = COMPACT ? r : j;                                 // (compact joints: one row per output row)
+      const int jj = (COMPACT && !byjoint) ? r : j;                   // (compact joints: one row per output row)
 #pragma unroll
       for (int c = 0; c < 3; c++) {
         if (ALIGN) {
@@ -567,6 +570,44 @@ int gmr_smplx_joints(gmr_smplx_t* h, int N, const double* j_rest, const float* f
   if (rc == GMR_OK) rc = gmr_smplx_joints_dev(h, N, h->d_jrest, d_pose, d_tr, d_j, nullptr);
   if (rc == GMR_OK && (e = hipMemcpy(joints, d_j, nb_pose, hipMemcpyDeviceToHost)) != hipSuccess)
     rc = gmr_fail(GMR_ERR_HIP, "gmr_smplx_joints: %s", hipGetErrorString(e));
+  return rc;
+}
+
+// Both steps for one clip, host buffers in and out, nothing but the packed frames coming back: poses up, transposed once,
+// the body model's joints written as planes, the alignment reading pose and joint planes by joint index -- no joints on
+// the host, no gather, no second upload (utils/smpl.py:12-41 + :109-197 in one call).  target_time == NULL: Nout == N.
+int gmr_smplx_frames(gmr_smplx_t* h, int N, const double* j_rest, const float* full_pose, const float* transl, int Nout,
+                     const double* target_time, double* out) {
+  if (!h || N < 1 || Nout < 0 || !j_rest || !full_pose || !transl || !out) return gmr_fail(GMR_ERR_ARG, "gmr_smplx_frames: bad argument");
+  if (!target_time && Nout != N) return gmr_fail(GMR_ERR_ARG, "gmr_smplx_frames: without target times Nout must equal N");
+  if (target_time && N < 2) return gmr_fail(GMR_ERR_ARG, "gmr_smplx_frames: fps alignment needs at least two source frames");
+  if (Nout == 0) return GMR_OK;
+  const int C = h->J * 3;
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  const size_t nb_pose = up((size_t)N * C * sizeof(float)), nb_tr = up((size_t)N * 3 * sizeof(float));
+  const size_t nb_t = up((size_t)Nout * sizeof(double)), nb_out = up((size_t)Nout * h->sel.nrow * 7 * sizeof(double));
+  std::lock_guard<std::mutex> guard(h->mu);
+  char* ws = nullptr;
+  hipError_t e = smplx_workspace(h, 3 * nb_pose + nb_tr + nb_t + nb_out, &ws);
+  if (e != hipSuccess) return gmr_fail(GMR_ERR_HIP, "gmr_smplx_frames: %s", hipGetErrorString(e));
+  float* d_pose = (float*)ws;
+  float* pose_t = (float*)(ws + nb_pose);
+  float* joints_t = (float*)(ws + 2 * nb_pose);
+  float* d_tr = (float*)(ws + 3 * nb_pose);
+  double* d_t = (double*)(ws + 3 * nb_pose + nb_tr);
+  double* d_o = (double*)(ws + 3 * nb_pose + nb_tr + nb_t);
+  if ((e = hipMemcpy(h->d_jrest, j_rest, (size_t)h->J * 3 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(d_pose, full_pose, (size_t)N * C * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
+      (e = hipMemcpy(d_tr, transl, (size_t)N * 3 * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
+      (target_time && (e = hipMemcpy(d_t, target_time, (size_t)Nout * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess))
+    return gmr_fail(GMR_ERR_HIP, "gmr_smplx_frames: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(gmr::transpose_f32_kernel, dim3((N + 63) / 64, (C + 63) / 64), dim3(256), 0, nullptr, d_pose, N, C, pose_t, 1);
+  hipLaunchKernelGGL(gmr::smplx_joints_kernel<true>, dim3((N + SX_BLOCK - 1) / SX_BLOCK), dim3(SX_BLOCK),
+                     std::max(h->all.nslot - 1, 1) * 12 * SX_BLOCK * 8, nullptr, h->all, N, h->d_jrest, pose_t, d_tr, joints_t);
+  if ((e = hipGetLastError()) != hipSuccess) return gmr_fail(GMR_ERR_HIP, "gmr_smplx_frames: %s", hipGetErrorString(e));
+  int rc = smplx_align_launch(h, true, N, -1, pose_t, joints_t, Nout, target_time ? d_t : nullptr, d_o, nullptr);
+  if (rc == GMR_OK && (e = hipMemcpy(out, d_o, (size_t)Nout * h->sel.nrow * 7 * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess)
+    rc = gmr_fail(GMR_ERR_HIP, "gmr_smplx_frames: %s", hipGetErrorString(e));
   return rc;
 }
 

@@ -624,13 +624,12 @@ def retarget_smplx_loaded(raws: Sequence[Dict], smplx_body_model_path: str, tgt_
     gmr_of: Dict[float, GeneralMotionRetargeting] = {}
     for i, d in enumerate(raws):
         bm = smpl.body_model_for(smplx_body_model_path, str(d["gender"]))
-        so = bm(betas=d["betas"], global_orient=d["root_orient"], body_pose=d["pose_body"], transl=d["trans"])
         betas = np.asarray(d["betas"])
         h = float(1.66 + 0.1 * (betas[0] if betas.ndim == 1 else betas[0, 0]))
         g = gmr_of.get(h)
         if g is None:
             g = gmr_of[h] = GeneralMotionRetargeting("smplx", tgt_robot, actual_human_height=h)
-        packed[i], fps_of[i] = smpl.smplx_frames_packed(g, d, bm, so, tgt_fps=tgt_fps)
+        packed[i], fps_of[i] = smpl.smplx_frames_packed_fused(g, d, bm, tgt_fps=tgt_fps)      # body model + alignment, one call
         height[i] = h
     jobs, members = [], []
     for h, g in gmr_of.items():

@@ -115,8 +115,9 @@ class SmplxBodyModel:
         b[: len(bb)] = bb
         return self.j_template + self.j_shapedirs @ b
 
-    def __call__(self, betas, global_orient, body_pose, transl, left_hand_pose=None, right_hand_pose=None,
-                 jaw_pose=None, leye_pose=None, reye_pose=None, return_full_pose=True, **_):
+    def full_pose(self, global_orient, body_pose, left_hand_pose=None, right_hand_pose=None, jaw_pose=None, leye_pose=None,
+                  reye_pose=None) -> np.ndarray:
+        """``full_pose`` f32[N, J, 3] of the forward pass (absent parts are zero, the hands' mean pose added)."""
         go = _np(global_orient, np.float32).reshape(-1, 3)
         N = go.shape[0]
         J = self.num_joints
@@ -125,7 +126,12 @@ class SmplxBodyModel:
             return np.zeros((N, n), np.float32) if x is None else _np(x, np.float32).reshape(N, n)
         full = np.concatenate([go, part(body_pose, 63), part(jaw_pose, 3), part(leye_pose, 3), part(reye_pose, 3),
                                part(left_hand_pose, 45), part(right_hand_pose, 45)], axis=1)[:, : 3 * J]
-        full = (full.reshape(N, J, 3) + self.pose_mean[None]).astype(np.float32)
+        return (full.reshape(N, J, 3) + self.pose_mean[None]).astype(np.float32)
+
+    def __call__(self, betas, global_orient, body_pose, transl, left_hand_pose=None, right_hand_pose=None,
+                 jaw_pose=None, leye_pose=None, reye_pose=None, return_full_pose=True, **_):
+        full = self.full_pose(global_orient, body_pose, left_hand_pose, right_hand_pose, jaw_pose, leye_pose, reye_pose)
+        N, J = full.shape[0], self.num_joints
         joints = _handle(self.parents).joints(self.rest_joints(_np(betas)), full, _np(transl, np.float32).reshape(N, 3))
         return SmplxOutput(global_orient=full[:, 0].copy(), full_pose=full.reshape(N, 3 * J), joints=joints)
 
@@ -229,3 +235,17 @@ def slerp(q1_xyzw, q2_xyzw, t):
         th0 = np.arccos(dot); th = th0 * t
         q = (np.cos(th) - dot * np.sin(th) / np.sin(th0)) * q1 + (np.sin(th) / np.sin(th0)) * q2
     return q / np.linalg.norm(q)
+
+
+def smplx_frames_packed_fused(retargeter, smplx_data, body_model, tgt_fps=30):
+    """:func:`smplx_frames_packed` straight from the file's arrays (``betas, root_orient, pose_body, trans,
+    mocap_frame_rate``): body model and alignment in ONE library call (``gmr_smplx_frames``), the joints never leave the
+    device.  Bit-identical to ``body_model(...)`` followed by :func:`smplx_frames_packed`."""
+    names = _names(body_model)
+    idx = {n: i for i, n in enumerate(names)}
+    sel = [idx[n] for n in retargeter.human_body_names]
+    full = body_model.full_pose(smplx_data["root_orient"], smplx_data["pose_body"])
+    tt, aligned_fps = _frame_counts(smplx_data, full.shape[0], tgt_fps)
+    frames = _handle(body_model.parents, sel).frames(body_model.rest_joints(_np(smplx_data["betas"])), full,
+                                                     _np(smplx_data["trans"], np.float32).reshape(full.shape[0], 3), tt)
+    return frames, aligned_fps

@@ -212,6 +212,12 @@ int gmr_smplx_align_dev(gmr_smplx_t* h, int N, int jstride, const float* d_full_
                         int Nout, const double* d_target_time, double* d_out, void* stream);
 int gmr_smplx_align(gmr_smplx_t* h, int N, int jstride, const float* full_pose, const float* joints, int Nout,
                     const double* target_time, double* out);
+/* Both steps for one clip in one call, host buffers: the body model's joints (all J) and the alignment of the selected rows,
+ * nothing but out f64[Nout][rows][7] coming back (no joints on the host, no gather between the steps).  Replaces
+ * load_smplx_file's forward pass + get_smplx_data_offline_fast (utils/smpl.py:12-41, :109-197) for a dataset driver that
+ * needs only the packed frames.  target_time == NULL: no fps alignment, Nout == N. */
+int gmr_smplx_frames(gmr_smplx_t* h, int N, const double* j_rest, const float* full_pose, const float* transl, int Nout,
+                     const double* target_time, double* out);
 /* The same on COMPACT inputs -- only what the alignment reads, FRAME-MINOR: pose_c f32[npose][3][N] = the axis-angle poses
  * of the selection's ancestor closure in walk order, joints_c f32[nrow][3][N] = the joint of every output row (numpy:
  * full_pose[:, pose_joints].transpose(1, 2, 0)); the two joint lists come from gmr_smplx_compact_layout (either output may
