@@ -1019,6 +1019,7 @@ struct WidePool {
   std::map<hipStream_t, QueueWs> ws;       // one workspace per HIP stream: launches on one stream are ordered
   int slots = 0;                           // resident wavefronts of the device (the queued grid)
   int chunk = 4;                           // frames per queue item (measured at nine streams per CU: 1: 15.0, 2: 15.7, 4: 15.8, 8: 15.2 M frames/s at 16 384 x 16)
+  bool chunk_auto = true;                  // nobody fixed it (GMR_IK_CHUNK, gmr_solver_set_dispatch): small launches halve it, below
   int min_streams_per_slot = 1;            // queued mode from slots * this + 1 streams (all resident: nothing to balance)
 };
 
@@ -1034,7 +1035,7 @@ extern "C" void* gmr_ik_wide_pool_create() {
   // (the API assumes 512-byte LDS granules; the device hands out 1 280-byte ones: tools/micro/lds_occupancy.hip)
   nblk = std::min(nblk, 160 * 1024 / ((wide_lds_launch_bytes() + gmr::WD_LDS_GRANULE - 1) / gmr::WD_LDS_GRANULE * gmr::WD_LDS_GRANULE));
   p->slots = ncu * nblk;
-  if (const char* e = getenv("GMR_IK_CHUNK")) p->chunk = atoi(e);      // 0 = always direct
+  if (const char* e = getenv("GMR_IK_CHUNK")) { p->chunk = atoi(e); p->chunk_auto = false; }      // 0 = always direct
   if (const char* e = getenv("GMR_IK_QUEUE_MIN")) p->min_streams_per_slot = std::max(1, atoi(e));
   return p;
 }
@@ -1043,6 +1044,7 @@ extern "C" void gmr_ik_wide_pool_set_chunk(void* pool, int chunk) {
   WidePool* p = static_cast<WidePool*>(pool);
   std::lock_guard<std::mutex> g(p->mu);
   p->chunk = chunk;
+  p->chunk_auto = false;
 }
 
 extern "C" void gmr_ik_wide_pool_destroy(void* pool) {
@@ -1083,7 +1085,8 @@ extern "C" hipError_t gmr_launch_ik_wide_window(const gmr_wide_job_desc* jd, int
   memset(&tab, 0, sizeof tab);
   long long total = 0, nring = 0;
   int chunk = 0, maxT = 0, n = 0;
-  if (p) { std::lock_guard<std::mutex> g(p->mu); chunk = p->chunk; }
+  bool chunk_auto = false;
+  if (p) { std::lock_guard<std::mutex> g(p->mu); chunk = p->chunk; chunk_auto = p->chunk_auto; }
   for (int j = 0; j < njobs; j++) {
     if (jd[j].S <= 0 || jd[j].T <= 0) continue;
     WideJob& J = tab.job[n++];
@@ -1112,6 +1115,10 @@ extern "C" hipError_t gmr_launch_ik_wide_window(const gmr_wide_job_desc* jd, int
     }
     return r;
   };
+  // A launch that is only a few rounds of items deep ends on a ragged last round: 16 384 streams x 8 frames -- an eighth of
+  // the 1M-frame batch, what one of eight GPUs gets -- is 14 rounds of 4-frame items on 2 304 resident wavefronts; with
+  // 2-frame items 28 rounds, 13.64 -> 14.18 M frames/s (32 768 x 8: 14.46 -> 14.63; 131 072 x 8 prefers 4: 14.98 vs 14.65)
+  if (chunk_auto && chunk == 4 && p && p->slots > 0 && ring_entries(4) < 24ll * p->slots) chunk = 2;
   while (chunk > 0 && chunk < span && ring_entries(chunk) > (1ll << 24)) chunk *= 2;
   // queued mode pays only when streams outnumber the resident wavefronts and have more than one chunk
   const bool queued = p && !d_prof && chunk > 0 && p->slots > 0 && span > chunk && total > (long long)p->slots * p->min_streams_per_slot;
