@@ -188,45 +188,58 @@ __global__ __launch_bounds__(SX_BLOCK) void smplx_align_kernel(SmplxProg P, int 
   }
 }
 
-// dst[C][R] = src[R][C]^T through 64 x 64 LDS tiles: both sides move whole lines.  The joints kernel reads its poses and
-// writes its joints as frame-minor planes [J * 3][N] -- lane = frame, so every load / store instruction is one contiguous run;
-// with frame-major rows a lane's 660-byte row stays open for the 200 us of its walk, and at eight blocks per CU the rows in
-// flight (100 MB) no longer fit the L2: 2.2 GB fetched and 3.0 GB written for 0.69 + 0.69 GB (measured, profiles/r03_v6_*).
-__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ src, int R, int C, float* __restrict__ dst,
-                                                            int rows_on_x) {
-  __shared__ float tile[64][65];
-  // (the frame dimension rides on blockIdx.x: no 65 535 limit)
-  const int c0 = (rows_on_x ? blockIdx.y : blockIdx.x) * 64, r0 = (rows_on_x ? blockIdx.x : blockIdx.y) * 64;
-  // 16 bytes per lane on both sides (dword-aligned vector accesses: a 660-byte row starts anywhere): lane group g = t >> 4
-  // takes a row of the tile, lane q = t & 15 four consecutive elements of it
+// Frame-major rows f32[N][C] <-> frame-minor planes f32[C][N] (C = J * 3 <= 256), 64 frames per block through one LDS tile.
+// The joints kernel reads its poses and writes its joints as planes -- lane = frame, so every load / store instruction is
+// one contiguous run; with frame-major rows a lane's 660-byte row stays open for the 200 us of its walk, and at eight or
+// more blocks per CU the rows in flight (100 MB) no longer fit the L2: 2.2 GB fetched and 3.0 GB written for 0.69 + 0.69 GB
+// (measured, profiles/r03_v6_*).  A block's 64 rows are ONE contiguous range of the row array (read / written flat, 16 bytes
+// per lane), its piece of a plane 256 bytes.  (First version: generic 64 x 64 tiles, whose row side moved 256-byte pieces of
+// 660-byte rows: 0.42 ms per 2^20 x 165 floats, 3.3 TB/s.)
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <bool TO_PLANES>
+__global__ __launch_bounds__(256) void rows_planes_kernel(const float* __restrict__ src, int N, int C, float* __restrict__ dst) {
+  extern __shared__ float tile[];                      // [64][C + 1]
+  const int r0 = blockIdx.x * 64, nr = min(64, N - r0), ld = C + 1, n = nr * C;
+  const unsigned magic = (1u << 24) / (unsigned)C + 1u; // e / C for e < 2^14, C <= 256
   const int q = (threadIdx.x & 15) * 4, g = threadIdx.x >> 4;
-  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  const float* rows_in = src + (size_t)r0 * C;          // TO_PLANES: flat rows in
+  float* rows_out = dst + (size_t)r0 * C;               // else: flat rows out
+  if (TO_PLANES) {
+    for (int i = threadIdx.x * 4; i < n; i += 1024) {
+      float v[4];
+      if (i + 3 < n) { const f4u t = *reinterpret_cast<const f4u*>(rows_in + i); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+      else for (int k = 0; k < 4; k++) v[k] = i + k < n ? rows_in[i + k] : 0.0f;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int r = r0 + g + 16 * i, c = c0 + q;
-    if (r < R) {
-      const float* p = src + (size_t)r * C + c;
-      if (c + 3 < C) {
-        const f4u v = *reinterpret_cast<const f4u*>(p);
-        tile[g + 16 * i][q] = v.x; tile[g + 16 * i][q + 1] = v.y; tile[g + 16 * i][q + 2] = v.z; tile[g + 16 * i][q + 3] = v.w;
-      } else {
-        for (int k = 0; k < 4 && c + k < C; k++) tile[g + 16 * i][q + k] = p[k];
+      for (int k = 0; k < 4; k++) {
+        const unsigned e = (unsigned)(i + k), r = (e * magic) >> 24;
+        if ((int)e < n) tile[r * ld + (e - r * C)] = v[k];
       }
+    }
+  } else {
+    for (int c = g; c < C; c += 16) {
+      const float* p = src + (size_t)c * N + r0 + q;
+      if (q + 3 < nr) { const f4u t = *reinterpret_cast<const f4u*>(p); tile[q * ld + c] = t.x; tile[(q + 1) * ld + c] = t.y; tile[(q + 2) * ld + c] = t.z; tile[(q + 3) * ld + c] = t.w; }
+      else for (int k = 0; k < 4 && q + k < nr; k++) tile[(q + k) * ld + c] = p[k];
     }
   }
   __syncthreads();
+  if (TO_PLANES) {
+    for (int c = g; c < C; c += 16) {
+      float* p = dst + (size_t)c * N + r0 + q;
+      if (q + 3 < nr) { f4u t; t.x = tile[q * ld + c]; t.y = tile[(q + 1) * ld + c]; t.z = tile[(q + 2) * ld + c]; t.w = tile[(q + 3) * ld + c]; *reinterpret_cast<f4u*>(p) = t; }
+      else for (int k = 0; k < 4 && q + k < nr; k++) p[k] = tile[(q + k) * ld + c];
+    }
+  } else {
+    for (int i = threadIdx.x * 4; i < n; i += 1024) {
+      float v[4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int c = c0 + g + 16 * i, r = r0 + q;
-    if (c < C) {
-      float* p = dst + (size_t)c * R + r;
-      if (r + 3 < R) {
-        f4u v;
-        v.x = tile[q][g + 16 * i]; v.y = tile[q + 1][g + 16 * i]; v.z = tile[q + 2][g + 16 * i]; v.w = tile[q + 3][g + 16 * i];
-        *reinterpret_cast<f4u*>(p) = v;
-      } else {
-        for (int k = 0; k < 4 && r + k < R; k++) p[k] = tile[q + k][g + 16 * i];
+      for (int k = 0; k < 4; k++) {
+        const unsigned e = (unsigned)(i + k), r = (e * magic) >> 24;
+        v[k] = (int)e < n ? tile[r * ld + (e - r * C)] : 0.0f;
       }
+      if (i + 3 < n) { f4u t; t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; *reinterpret_cast<f4u*>(rows_out + i) = t; }
+      else for (int k = 0; k < 4 && i + k < n; k++) rows_out[i + k] = v[k];
     }
   }
 }
@@ -496,9 +509,9 @@ int gmr_smplx_joints_dev(gmr_smplx_t* h, int N, const double* d_j_rest, const fl
     }
     float* pose_t = reinterpret_cast<float*>(h->planes);
     float* joints_t = reinterpret_cast<float*>(h->planes + h->planes_bytes / 2 / 256 * 256);
-    hipLaunchKernelGGL(gmr::transpose_f32_kernel, dim3((N + 63) / 64, (C + 63) / 64), dim3(256), 0, st, d_full_pose, N, C, pose_t, 1);
+    hipLaunchKernelGGL(gmr::rows_planes_kernel<true>, dim3((N + 63) / 64), dim3(256), 64 * (C + 1) * sizeof(float), st, d_full_pose, N, C, pose_t);
     hipLaunchKernelGGL(gmr::smplx_joints_kernel<true>, grid, block, lds, st, h->all, N, d_j_rest, pose_t, d_transl, joints_t);
-    hipLaunchKernelGGL(gmr::transpose_f32_kernel, dim3((N + 63) / 64, (C + 63) / 64), dim3(256), 0, st, joints_t, C, N, d_joints, 0);
+    hipLaunchKernelGGL(gmr::rows_planes_kernel<false>, dim3((N + 63) / 64), dim3(256), 64 * (C + 1) * sizeof(float), st, joints_t, N, C, d_joints);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return gmr_fail(GMR_ERR_HIP, "smplx_joints_kernel: %s", hipGetErrorString(e));
@@ -601,7 +614,7 @@ int gmr_smplx_frames(gmr_smplx_t* h, int N, const double* j_rest, const float* f
       (e = hipMemcpy(d_tr, transl, (size_t)N * 3 * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess ||
       (target_time && (e = hipMemcpy(d_t, target_time, (size_t)Nout * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess))
     return gmr_fail(GMR_ERR_HIP, "gmr_smplx_frames: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(gmr::transpose_f32_kernel, dim3((N + 63) / 64, (C + 63) / 64), dim3(256), 0, nullptr, d_pose, N, C, pose_t, 1);
+  hipLaunchKernelGGL(gmr::rows_planes_kernel<true>, dim3((N + 63) / 64), dim3(256), 64 * (C + 1) * sizeof(float), nullptr, d_pose, N, C, pose_t);
   hipLaunchKernelGGL(gmr::smplx_joints_kernel<true>, dim3((N + SX_BLOCK - 1) / SX_BLOCK), dim3(SX_BLOCK),
                      std::max(h->all.nslot - 1, 1) * 12 * SX_BLOCK * 8, nullptr, h->all, N, h->d_jrest, pose_t, d_tr, joints_t);
   if ((e = hipGetLastError()) != hipSuccess) return gmr_fail(GMR_ERR_HIP, "gmr_smplx_frames: %s", hipGetErrorString(e));
